@@ -1,0 +1,172 @@
+/*
+ * lpipm.h -- C ABI of the MI355X-native interior-point LP hot path (liblpipm.so).
+ *
+ * Drop-in boundary for the ONE hot path of sebasv/lp (crate `ripped` 0.1.1):
+ * `InteriorPoint::solve()` on a slack-form `Problem` -- forming A.diag(x/z).A^T, its Cholesky
+ * factor, the triangular solves and the residual / direction GEMVs of the homogeneous self-dual
+ * Mehrotra predictor-corrector algorithm -- as hand-written HIP kernels for gfx950.
+ *
+ * The reference has no FFI; each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/src).  Plain pointers and sizes only; no C++/torch types.
+ * The reference-side binding a maintainer would add (a `hip` feature arm next to
+ * `cfg(feature = "blas")`, newton_equations.rs:2-13) is shown in INTEGRATION.md and
+ * bindings/rust/.
+ *
+ * Conventions
+ *   - every function returns an lpipm_status (0 = Ok) unless stated otherwise;
+ *   - the caller owns every host pointer; the library copies in, never retains a host pointer
+ *     after return, never calls back, never unwinds across the boundary;
+ *   - a ctx is bound to one device and one stream and is not thread-safe; distinct ctxs are
+ *     independent (one per GPU for batches);
+ *   - matrices are row-major fp64, exactly as `Problem` holds them (ndarray standard layout,
+ *     linear_program.rs:145-156).
+ */
+#ifndef LPIPM_H
+#define LPIPM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error.rs:10-28 (LinearProgramError) as integers; >= 100 have no reference analogue. */
+typedef enum {
+    LPIPM_OK                      = 0,
+    LPIPM_UNCONSTRAINED           = 1, /* error.rs:12  */
+    LPIPM_NUMERICAL_PROBLEM       = 2, /* error.rs:15  */
+    LPIPM_INVALID_PARAMETER       = 3, /* error.rs:18  */
+    LPIPM_INCOMPATIBLE_DIMENSIONS = 4, /* error.rs:21  */
+    LPIPM_INFEASIBLE              = 5, /* error.rs:24  */
+    LPIPM_UNBOUNDED               = 6, /* error.rs:27  */
+    LPIPM_ITERATION_LIMIT         = 7, /* error.rs:28  IterationLimitExceeded(x / tau): x_out IS filled */
+    LPIPM_ERR_HIP                 = 100, /* HIP runtime failure (lpipm_last_error_detail has the text) */
+    LPIPM_ERR_NO_PROBLEM          = 101, /* solve before upload */
+    LPIPM_ERR_UNSUPPORTED         = 102, /* valid in the reference, not built here yet */
+    LPIPM_ERR_BAD_ARGUMENT        = 103  /* null pointer / lda < n / size overflow */
+} lpipm_status;
+
+/* solvers/interior_point/newton_equations.rs:37-46 (EquationSolverType) */
+enum { LPIPM_SOLVER_CHOLESKY = 0, LPIPM_SOLVER_INVERSE = 1, LPIPM_SOLVER_LEAST_SQUARES = 2 };
+
+/* solvers/interior_point/mod.rs:41-48 (InteriorPointBuilder / InteriorPoint fields) */
+typedef struct {
+    double   tol;         /* mod.rs:53  default 1e-8    ; must be > 0        (mod.rs:124) */
+    double   alpha0;      /* mod.rs:57  default 0.99995 ; 0 < alpha0 < 1     (mod.rs:119) */
+    uint64_t max_iter;    /* mod.rs:58  default 1000 */
+    int32_t  ip;          /* mod.rs:55  default 1 (alternative initial point) */
+    int32_t  solver_type; /* mod.rs:56  default LPIPM_SOLVER_CHOLESKY */
+    int32_t  disp;        /* mod.rs:54  default 0; 1 prints the reference's table (mod.rs:208-211,227-229) */
+} lpipm_opts;
+
+/* One row of the `disp` table: alpha (mod.rs:228) + Indicators (indicators.rs:8-23). */
+typedef struct { double alpha, rho_p, rho_d, rho_A, rho_g, rho_mu, obj; } lpipm_iter_row;
+
+/* Device time per phase of the LAST lpipm_solve on this ctx, from HIP events on the ctx's stream
+ * (only filled while profiling is on; recording events costs a few us per phase). */
+typedef struct {
+    double   adat_ms;      /* sum over iterations of the A.D.A^T kernel launches       */
+    double   potrf_ms;     /* Cholesky factorisation (+ diagonal-block inverses)        */
+    double   trsv_ms;      /* triangular solves                                        */
+    double   gemv_ms;      /* passes over A (GEMV-N / GEMV-T)                           */
+    double   vec_ms;       /* O(n) vector / scalar kernels + status read-back          */
+    double   total_ms;     /* first kernel to last kernel of the solve                 */
+    uint64_t adat_launches;
+    uint64_t iterations;
+} lpipm_phase_times;
+
+typedef struct lpipm_ctx lpipm_ctx; /* opaque: device buffers + stream for one (thread, device) */
+
+/* InteriorPointBuilder::new (mod.rs:50-60) */
+void lpipm_default_opts(lpipm_opts* out);
+/* Display strings of error.rs:10-28 (+ the >= 100 codes).  Never NULL. */
+const char* lpipm_strerror(int status);
+/* Text of the last HIP failure on this thread ("" if none). */
+const char* lpipm_last_error_detail(void);
+/* Number of visible HIP devices (0 when there is no GPU or no driver). */
+int lpipm_device_count(void);
+
+/* ProblemBuilder::build (linear_program.rs:125-169): slack form
+ *   A = [[A_ub I],[A_eq 0]]  ((m_ub+m_eq) x (n+m_ub)),  b = [b_ub; b_eq],  c = [c; 0].
+ * Host-side, O(mn), once per problem.  A_ub / A_eq may be NULL when their row count is 0.
+ * Outputs must hold (m_ub+m_eq)*(n+m_ub), (m_ub+m_eq) and (n+m_ub) doubles. */
+int lpipm_problem_build(uint64_t n, uint64_t m_ub, const double* A_ub, const double* b_ub,
+                        uint64_t m_eq, const double* A_eq, const double* b_eq, const double* c,
+                        double* A_out, double* b_out, double* c_out, uint64_t* n_slack_out);
+
+/* One context per (thread, device).  Fails with LPIPM_ERR_HIP when the device is unusable:
+ * there is NO CPU fallback anywhere behind this ABI. */
+int  lpipm_create(int device, lpipm_ctx** out);
+void lpipm_destroy(lpipm_ctx* ctx);
+
+/* Upload the slack-form problem `Problem` holds (accessors A() b() c(), linear_program.rs:42-59;
+ * c0 :56-59).  A is m x n row-major with leading dimension lda >= n.  One H2D copy of A; the
+ * hot loop never touches host memory again except a 96-byte status read-back per iteration. */
+int lpipm_upload(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A, uint64_t lda,
+                 const double* b, const double* c, double c0);
+
+/* InteriorPoint::solve_normal_form + the `fun` of solve (mod.rs:199-240, :165).
+ *   x_slack_out[n] : x / tau  (mod.rs:231); ALSO filled for LPIPM_ITERATION_LIMIT (mod.rs:237-239)
+ *   fun_out        : c . x_slack + c0  (linear_program.rs:61-63)
+ *   iterations_out : iteration at which the status was decided (mod.rs:213,231)
+ *   log            : nullable; one row per iteration, at most max_iter rows
+ * Dropping the n_slack tail (denormalize_x_into, linear_program.rs:65-69) stays with the caller,
+ * where the reference has it (mod.rs:166).  Option validation mirrors mod.rs:118-128. */
+int lpipm_solve(lpipm_ctx* ctx, const lpipm_opts* opts, double* x_slack_out, double* fun_out,
+                uint64_t* iterations_out, lpipm_iter_row* log);
+
+/* Same solve, solution left in HBM: copies x / tau (n doubles) to a DEVICE pointer on the ctx's
+ * stream (for the one RCCL gather of a sharded batch); x_dev_out may be NULL. */
+int lpipm_solve_device(lpipm_ctx* ctx, const lpipm_opts* opts, void* x_dev_out, double* fun_out,
+                       uint64_t* iterations_out, lpipm_iter_row* log);
+
+/* A shard of independent LPs on ONE device (BASELINE config 4): problem i is m[i] x n[i] with
+ * A[i] (lda = n[i]), b[i], c[i], c0[i]; results go to x_slack_out[i] (n[i] doubles), fun_out[i],
+ * iterations_out[i], status_out[i].  Returns the first non-Ok *runtime* status (>= 100) or Ok;
+ * per-problem solver outcomes (Infeasible, ...) are reported in status_out only. */
+int lpipm_solve_batch(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const uint64_t* n,
+                      const double* const* A, const double* const* b, const double* const* c,
+                      const double* c0, const lpipm_opts* opts, double* const* x_slack_out,
+                      double* fun_out, uint64_t* iterations_out, int32_t* status_out);
+
+/* Profiling switch (off by default) and the per-phase device times of the last solve. */
+int lpipm_set_profiling(lpipm_ctx* ctx, int on);
+int lpipm_get_phase_times(const lpipm_ctx* ctx, lpipm_phase_times* out);
+
+/* ---- kernel-granularity entry points ---------------------------------------------------------
+ * Each runs ONE stage of the hot path on the uploaded problem / the given operands so that the
+ * parity tests can compare it with the oracle's restatement of the cited reference lines.
+ * Host pointers in, host pointers out (copies are outside any timing the library reports). */
+
+/* newton_equations.rs:54-57:  M = A . diag(dinv) . A^T.  dinv[n]; M_out m x m row-major, LOWER
+ * triangle valid (the strict upper triangle is unspecified).  `ms_out` (nullable) gets the device
+ * time of the kernel launch(es) averaged over `repeats` (>= 1) back-to-back launches. */
+int lpipm_k_adat(lpipm_ctx* ctx, const double* dinv, double* M_out, int repeats, double* ms_out);
+/* newton_equations.rs:129-131: in-place lower Cholesky of the m x m row-major matrix M (lower
+ * triangle read, lower triangle written).  info_out: 0, or k+1 for the first non-positive pivot. */
+int lpipm_k_potrf(lpipm_ctx* ctx, uint64_t m, double* M_inout, int32_t* info_out, int repeats,
+                  double* ms_out);
+/* newton_equations.rs:151-169: V[r] = L^-T L^-1 R[r] for nrhs (1 or 2) right-hand sides, with
+ * L = the factor of a preceding lpipm_k_potrf on this ctx (kept on device).  R, V: nrhs x m. */
+int lpipm_k_chol_solve(lpipm_ctx* ctx, uint64_t m, int nrhs, const double* R, double* V,
+                       int repeats, double* ms_out);
+/* A.w (feasible_point.rs:122, newton_equations.rs:220, residual.rs:23): nrhs (1|2) vectors,
+ * W nrhs x n -> Y nrhs x m. */
+int lpipm_k_gemv_n(lpipm_ctx* ctx, int nrhs, const double* W, double* Y, int repeats, double* ms_out);
+/* A^T.v (feasible_point.rs:123, newton_equations.rs:223, residual.rs:25): V nrhs x m -> U nrhs x n */
+int lpipm_k_gemv_t(lpipm_ctx* ctx, int nrhs, const double* V, double* U, int repeats, double* ms_out);
+/* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64 back to back, operands in registers):
+ * tflops_out = achieved TFLOP/s over the whole chip; used to confirm the roofline denominator. */
+int lpipm_k_mfma_f64_probe(lpipm_ctx* ctx, int iters, double* tflops_out, double* ms_out);
+
+/* ---- synthetic inputs (SURVEY.md 8d / BASELINE.md 3) -----------------------------------------
+ * Equality-form planted LP with a strictly complementary optimum: A_ij ~ N(0,1); basis B of m
+ * columns; x*_B ~ U(1,2), x*_N = 0; y* ~ N(0,1); z*_N ~ U(1,2), z*_B = 0; b = A x*, c = A^T y* + z*.
+ * splitmix64 -> xoshiro256**, Box-Muller, Fisher-Yates.  Host-side; A m x n row-major.
+ * xstar_out (n) is nullable. */
+int lpipm_synth_planted_lp(uint64_t seed, uint64_t m, uint64_t n, double* A_out, double* b_out,
+                           double* c_out, double* xstar_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPIPM_H */

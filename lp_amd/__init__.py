@@ -1,0 +1,408 @@
+"""lp_amd -- MI355X-native interior-point LP hot path behind the reference's own API.
+
+Host-side mirror (Python, over the C ABI of include/lpipm.h) of the public interface of
+sebasv/lp (crate `ripped` 0.1.1) for the one path this package accelerates:
+
+    reference (Rust)                                   here
+    -----------------------------------------------    ------------------------------------------
+    Problem::target(&c).ub(&A,&b).eq(&A,&b).build()    Problem.target(c).ub(A, b).eq(A, b).build()
+    InteriorPoint::default()                           InteriorPoint.default()
+    InteriorPoint::custom().tol(..)...build()          InteriorPoint.custom().tol(..)...build()
+    solver.solve(&problem) -> Result<OptimizeResult>   solver.solve(problem) -> OptimizeResult | raises
+    res.x() / res.fun() / res.iteration()              res.x() / res.fun() / res.iteration()
+    LinearProgramError::{Unconstrained, ...}           LinearProgramError subclasses of the same names
+
+(src/linear_program.rs:24-170, src/solvers/mod.rs:12-49, src/solvers/interior_point/mod.rs:41-197,
+src/error.rs:7-29.)  A Rust `Result::Err(e)` becomes a raised exception of the matching class.
+All numerics run in liblpipm.so on the GPU; importing this package never imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["Problem", "ProblemBuilder", "InteriorPoint", "InteriorPointBuilder", "EquationSolverType",
+           "OptimizeResult", "Solver", "Context", "LinearProgramError", "Unconstrained",
+           "NumericalProblem", "InvalidParameter", "IncompatibleInputDimensions", "Infeasible",
+           "Unbounded", "IterationLimitExceeded", "BackendError"]
+
+
+# ------------------------------------------------------------------------------ error.rs:7-29
+class LinearProgramError(Exception):
+    """error.rs:10-28.  `code` is the lpipm_status the C ABI returned."""
+    code = -1
+
+    def __init__(self, msg: str | None = None):
+        super().__init__(msg if msg is not None else _capi.strerror(self.code))
+
+
+class Unconstrained(LinearProgramError):
+    code = _capi.UNCONSTRAINED
+
+
+class NumericalProblem(LinearProgramError):
+    code = _capi.NUMERICAL_PROBLEM
+
+
+class InvalidParameter(LinearProgramError):
+    code = _capi.INVALID_PARAMETER
+
+    def __init__(self, what: str = ""):
+        super().__init__(f"A parameter was set to an invalid value: {what}")
+
+
+class IncompatibleInputDimensions(LinearProgramError):
+    code = _capi.INCOMPATIBLE_DIMENSIONS
+
+
+class Infeasible(LinearProgramError):
+    code = _capi.INFEASIBLE
+
+
+class Unbounded(LinearProgramError):
+    code = _capi.UNBOUNDED
+
+
+class IterationLimitExceeded(LinearProgramError):
+    """error.rs:26-28: carries the best x / tau after the final iteration (mod.rs:237-239)."""
+    code = _capi.ITERATION_LIMIT
+
+    def __init__(self, x: np.ndarray):
+        super().__init__()
+        self.x = x
+
+
+class BackendError(RuntimeError):
+    """HIP/driver failure (status >= 100): no analogue in the reference; never silently ignored."""
+
+
+_BY_CODE = {c.code: c for c in (Unconstrained, NumericalProblem, IncompatibleInputDimensions, Infeasible, Unbounded)}
+
+
+def _raise_for(code: int, x=None):
+    if code == _capi.OK:
+        return
+    if code == _capi.ITERATION_LIMIT:
+        raise IterationLimitExceeded(x)
+    if code == _capi.INVALID_PARAMETER:
+        raise InvalidParameter("rejected by the backend")
+    if code in _BY_CODE:
+        raise _BY_CODE[code]()
+    raise BackendError(f"lpipm status {code}: {_capi.strerror(code)} {_capi.last_error_detail()}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ------------------------------------------------------------------------------ linear_program.rs
+class Problem:
+    """A linear program in slack form (linear_program.rs:24-30): min c'x st A x == b, x >= 0."""
+
+    def __init__(self, A, b, c, c0, n_slack):
+        self._A, self._b, self._c, self._c0, self._n_slack = A, b, c, float(c0), int(n_slack)
+
+    @staticmethod
+    def target(c) -> "ProblemBuilder":          # linear_program.rs:37-39
+        return ProblemBuilder(c)
+
+    def A(self) -> np.ndarray:                   # :42-44
+        return self._A
+
+    def b(self) -> np.ndarray:                   # :47-49
+        return self._b
+
+    def c(self) -> np.ndarray:                   # :52-54
+        return self._c
+
+    def c0(self) -> float:                       # :57-59
+        return self._c0
+
+    def n_slack(self) -> int:
+        return self._n_slack
+
+    def denormalize_x_into(self, x_slack: np.ndarray) -> np.ndarray:   # :65-69
+        return np.array(x_slack[: x_slack.shape[0] - self._n_slack])
+
+
+class ProblemBuilder:
+    """linear_program.rs:72-170."""
+
+    def __init__(self, c):
+        self._c = c
+        self._ub = None
+        self._eq = None
+
+    def ub(self, A, b) -> "ProblemBuilder":      # :93-96
+        self._ub = (A, b)
+        return self
+
+    def eq(self, A, b) -> "ProblemBuilder":      # :102-105
+        self._eq = (A, b)
+        return self
+
+    def build(self) -> Problem:                  # :125-169
+        c = _f64(self._c)
+        if c.ndim != 1:
+            raise IncompatibleInputDimensions()
+        n = c.shape[0]
+        A_ub, b_ub = self._ub if self._ub is not None else (np.zeros((0, n)), np.zeros(0))
+        A_eq, b_eq = self._eq if self._eq is not None else (np.zeros((0, n)), np.zeros(0))
+        A_ub, b_ub, A_eq, b_eq = _f64(A_ub), _f64(b_ub), _f64(A_eq), _f64(b_eq)
+        if A_ub.ndim != 2 or A_eq.ndim != 2 or b_ub.ndim != 1 or b_eq.ndim != 1:
+            raise IncompatibleInputDimensions()
+        m_ub, m_eq = A_ub.shape[0], A_eq.shape[0]
+        if m_ub + m_eq == 0:                                                 # :134-136
+            raise Unconstrained()
+        if (A_ub.shape[1] != A_eq.shape[1] or A_eq.shape[1] != n or m_ub != b_ub.shape[0]
+                or m_eq != b_eq.shape[0]):                                   # :137-143
+            raise IncompatibleInputDimensions()
+        m, ns = m_ub + m_eq, n + m_ub
+        A = np.empty((m, ns))
+        b = np.empty(m)
+        cs = np.empty(ns)
+        nsl = C.c_uint64(0)
+        rc = _capi.lib().lpipm_problem_build(n, m_ub, _p(A_ub) if m_ub else None, _p(b_ub) if m_ub else None,
+                                             m_eq, _p(A_eq) if m_eq else None, _p(b_eq) if m_eq else None,
+                                             _p(c), _p(A), _p(b), _p(cs), C.byref(nsl))
+        _raise_for(rc)
+        return Problem(A, b, cs, 0.0, nsl.value)
+
+
+# ------------------------------------------------------------------------------ solvers/mod.rs
+class OptimizeResult:
+    """solvers/mod.rs:19-49."""
+
+    def __init__(self, x, fun, iteration):
+        self._x, self._fun, self._iteration = x, float(fun), int(iteration)
+
+    def iteration(self) -> int:
+        return self._iteration
+
+    def fun(self) -> float:
+        return self._fun
+
+    def x(self) -> np.ndarray:
+        return self._x
+
+
+class Solver:
+    """solvers/mod.rs:12-16."""
+
+    def solve(self, problem: Problem) -> OptimizeResult:
+        raise NotImplementedError
+
+
+class EquationSolverType(enum.IntEnum):
+    """newton_equations.rs:37-46."""
+    Cholesky = 0
+    Inverse = 1
+    LeastSquares = 2
+
+
+# ------------------------------------------------------------------------------ device context
+class Context:
+    """One lpipm_ctx: device buffers + stream of one (thread, device).  `InteriorPoint.solve` keeps one
+    per device; bench/tests use it directly to separate the one-time upload from the timed solve."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = _capi.lib().lpipm_create(int(device), C.byref(self._h))
+        if rc != _capi.OK:
+            raise BackendError(f"lpipm_create(device={device}) failed: {_capi.strerror(rc)}: "
+                               f"{_capi.last_error_detail()} -- a HIP device is required, there is no CPU path")
+        self.device = int(device)
+        self.n = self.m = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _capi.lib().lpipm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, problem: Problem):
+        A, b, c = _f64(problem.A()), _f64(problem.b()), _f64(problem.c())
+        return self.upload_arrays(A, b, c, problem.c0())
+
+    def upload_arrays(self, A, b, c, c0=0.0):
+        A, b, c = _f64(A), _f64(b), _f64(c)
+        if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
+            raise IncompatibleInputDimensions()
+        m, n = A.shape
+        rc = _capi.lib().lpipm_upload(self._h, m, n, _p(A), n, _p(b), _p(c), float(c0))
+        _raise_for(rc)
+        self.m, self.n = m, n
+        return self
+
+    def solve_raw(self, opts: "_capi.Opts", want_log: bool = False, x_dev_ptr: int | None = None):
+        """-> (status, x_slack | None, fun, iterations, log rows)"""
+        x = None if x_dev_ptr is not None else np.full(self.n, np.nan)
+        fun, it = C.c_double(np.nan), C.c_uint64(0)
+        nlog = int(min(opts.max_iter, 1 << 20)) if want_log else 0
+        log = (_capi.IterRow * max(nlog, 1))() if want_log else None
+        if x_dev_ptr is not None:
+            rc = _capi.lib().lpipm_solve_device(self._h, C.byref(opts), C.c_void_p(int(x_dev_ptr)), C.byref(fun),
+                                                C.byref(it), log)
+        else:
+            rc = _capi.lib().lpipm_solve(self._h, C.byref(opts), _p(x), C.byref(fun), C.byref(it), log)
+        rows = []
+        if want_log:
+            for i in range(min(int(it.value), nlog)):
+                r = log[i]
+                rows.append((r.alpha, r.rho_p, r.rho_d, r.rho_A, r.rho_g, r.rho_mu, r.obj))
+        return rc, x, fun.value, int(it.value), rows
+
+    def set_profiling(self, on: bool):
+        _capi.lib().lpipm_set_profiling(self._h, 1 if on else 0)
+
+    def phase_times(self) -> dict:
+        t = _capi.PhaseTimes()
+        _capi.lib().lpipm_get_phase_times(self._h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in _capi.PhaseTimes._fields_}
+
+    # ---- kernel-granularity entry points (parity tests / micro-benchmarks)
+    def k_adat(self, dinv, repeats=1):
+        dinv = _f64(dinv)
+        M = np.empty((self.m, self.m))
+        ms = C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_adat(self._h, _p(dinv), _p(M), repeats, C.byref(ms)))
+        return M, ms.value
+
+    def k_potrf(self, M, repeats=1):
+        L = _f64(M).copy()
+        info, ms = C.c_int32(0), C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_potrf(self._h, L.shape[0], _p(L), C.byref(info), repeats, C.byref(ms)))
+        return L, info.value, ms.value
+
+    def k_chol_solve(self, m, R, repeats=1):
+        R = np.atleast_2d(_f64(R))
+        V = np.empty_like(R)
+        ms = C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_chol_solve(self._h, m, R.shape[0], _p(R), _p(V), repeats, C.byref(ms)))
+        return V, ms.value
+
+    def k_gemv_n(self, W, repeats=1):
+        W = np.atleast_2d(_f64(W))
+        Y = np.empty((W.shape[0], self.m))
+        ms = C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_gemv_n(self._h, W.shape[0], _p(W), _p(Y), repeats, C.byref(ms)))
+        return Y, ms.value
+
+    def k_gemv_t(self, V, repeats=1):
+        V = np.atleast_2d(_f64(V))
+        U = np.empty((V.shape[0], self.n))
+        ms = C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_gemv_t(self._h, V.shape[0], _p(V), _p(U), repeats, C.byref(ms)))
+        return U, ms.value
+
+    def k_mfma_f64_probe(self, iters=20000):
+        tf, ms = C.c_double(0), C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_mfma_f64_probe(self._h, iters, C.byref(tf), C.byref(ms)))
+        return tf.value, ms.value
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ------------------------------------------------------------------------------ interior_point/mod.rs
+class InteriorPointBuilder:
+    """interior_point/mod.rs:41-138."""
+
+    def __init__(self):
+        o = _capi.Opts()
+        _capi.lib().lpipm_default_opts(C.byref(o))   # mod.rs:50-60
+        self._tol, self._disp, self._ip = o.tol, bool(o.disp), bool(o.ip)
+        self._solver_type, self._alpha0, self._max_iter = EquationSolverType(o.solver_type), o.alpha0, o.max_iter
+
+    def tol(self, tol):
+        self._tol = float(tol)
+        return self
+
+    def disp(self, disp):
+        self._disp = bool(disp)
+        return self
+
+    def ip(self, ip):
+        self._ip = bool(ip)
+        return self
+
+    def solver_type(self, solver_type):
+        self._solver_type = EquationSolverType(solver_type)
+        return self
+
+    def alpha0(self, alpha0):
+        self._alpha0 = float(alpha0)
+        return self
+
+    def max_iter(self, max_iter):
+        self._max_iter = int(max_iter)
+        return self
+
+    def build(self) -> "InteriorPoint":           # mod.rs:118-137
+        if self._alpha0 <= 0.0 or self._alpha0 >= 1.0:
+            raise InvalidParameter("Alpha0 must be between 0 and 1 (exclusive)")
+        if self._tol <= 0.0:
+            raise InvalidParameter("The tolerance must be nonnegative.")
+        return InteriorPoint(self._tol, self._disp, self._ip, self._solver_type, self._alpha0, self._max_iter)
+
+
+class InteriorPoint(Solver):
+    """interior_point/mod.rs:140-241.  `device` selects the GPU (no reference analogue; default 0)."""
+
+    def __init__(self, tol, disp, ip, solver_type, alpha0, max_iter, device: int = 0):
+        self._tol, self._disp, self._ip = tol, disp, ip
+        self._solver_type, self._alpha0, self._max_iter = solver_type, alpha0, max_iter
+        self.device = device
+
+    @staticmethod
+    def default() -> "InteriorPoint":             # mod.rs:154-159
+        return InteriorPointBuilder().build()
+
+    @staticmethod
+    def custom() -> InteriorPointBuilder:         # mod.rs:195-197
+        return InteriorPointBuilder()
+
+    def __eq__(self, other):                      # derive(PartialEq), mod.rs:140
+        return isinstance(other, InteriorPoint) and self._key() == other._key()
+
+    def _key(self):
+        return (self._tol, self._disp, self._ip, self._solver_type, self._alpha0, self._max_iter)
+
+    def opts(self) -> "_capi.Opts":
+        return _capi.Opts(self._tol, self._alpha0, self._max_iter, int(self._ip), int(self._solver_type),
+                          int(self._disp))
+
+    def solve(self, problem: Problem) -> OptimizeResult:     # mod.rs:161-168
+        ctx = default_context(self.device)
+        ctx.upload(problem)
+        return self.solve_uploaded(ctx, problem)
+
+    def solve_uploaded(self, ctx: Context, problem: Problem, want_log=False):
+        rc, x_slack, fun, it, rows = ctx.solve_raw(self.opts(), want_log=want_log)
+        if rc == _capi.ITERATION_LIMIT:
+            raise IterationLimitExceeded(x_slack)            # mod.rs:237-239 (payload: x / tau, slack form)
+        _raise_for(rc)
+        res = OptimizeResult(problem.denormalize_x_into(x_slack), fun, it)   # mod.rs:165-167
+        if want_log:
+            res.log = rows
+            res.x_slack = x_slack
+        return res

@@ -1,0 +1,141 @@
+// kernels_gemv.hip -- passes over A for the residual / direction GEMVs (HBM-bound).
+//
+//   gemv_n : y = add + A.w      feasible_point.rs:122 (r_P), newton_equations.rs:220 (sym_solve r),
+//                               residual.rs:23
+//   gemv_t : u = A^T.v          feasible_point.rs:123 (r_D), newton_equations.rs:223 (sym_solve u),
+//                               residual.rs:25
+// Both take 1 or 2 vectors per pass: the predictor's two sym_solve calls (newton_equations.rs:
+// 187-188) read A once instead of twice.  Coalescing: every wave instruction reads 64 lanes x 16 B
+// of ONE row of the row-major A.  Reductions are fixed-order (shuffle butterfly / split slabs
+// summed in index order) so results are bitwise reproducible run to run.
+#include "lpipm_internal.hpp"
+
+namespace lpipm {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int GN_ROWS_PER_WAVE = 2;
+constexpr int GN_ROWS_PER_WG   = 4 * GN_ROWS_PER_WAVE;
+
+// One wave computes GN_ROWS_PER_WAVE row dot products; np (padded row length) is a multiple of 16,
+// W is zero beyond the true n, so the 128-wide strides need a tail guard only on np.
+template <int NRHS>
+__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, long long lda, int m,
+                                                     int np, const double* __restrict__ W, long long ldw,
+                                                     const double* __restrict__ add0,
+                                                     const double* __restrict__ add1,
+                                                     double* __restrict__ Y, long long ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * GN_ROWS_PER_WG + wave * GN_ROWS_PER_WAVE;
+    if (row0 >= m) return;
+    double acc[GN_ROWS_PER_WAVE][NRHS];
+#pragma unroll
+    for (int r = 0; r < GN_ROWS_PER_WAVE; ++r)
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) acc[r][q] = 0.0;
+    const double* a0 = A + (long long)row0 * lda;
+    for (int k = 2 * lane; k < np; k += 128) {
+        d2 wv[NRHS];
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) wv[q] = *(const d2*)(W + (long long)q * ldw + k);
+#pragma unroll
+        for (int r = 0; r < GN_ROWS_PER_WAVE; ++r) {
+            // rows past m (only in the last workgroup) re-read row m-1; their result is not stored
+            const int rr = row0 + r < m ? r : 0;
+            const d2 av = *(const d2*)(a0 + (long long)rr * lda + k);
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) acc[r][q] += av[0] * wv[q][0] + av[1] * wv[q][1];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < GN_ROWS_PER_WAVE; ++r)
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) acc[r][q] += __shfl_xor(acc[r][q], off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < GN_ROWS_PER_WAVE; ++r) {
+            if (row0 + r >= m) continue;
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) {
+                const double* add = q == 0 ? add0 : add1;
+                const double base = add ? add[row0 + r] : 0.0;
+                Y[(long long)q * ldy + row0 + r] = base + acc[r][q];
+            }
+        }
+    }
+}
+
+// grid = (np / 512 rounded up, mp / GEMVT_ROWS).  Each thread owns two adjacent columns and walks
+// GEMVT_ROWS rows; the row split s = blockIdx.y writes its slab Upart[s][q][:].
+template <int NRHS>
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, long long lda, int np,
+                                                     const double* __restrict__ V, long long ldv,
+                                                     double* __restrict__ Upart) {
+    __shared__ double vs[NRHS][GEMVT_ROWS];
+    const int tid = threadIdx.x;
+    const int col = (blockIdx.x * 256 + tid) * 2;
+    const int row0 = blockIdx.y * GEMVT_ROWS;
+    for (int e = tid; e < NRHS * GEMVT_ROWS; e += 256)
+        vs[e / GEMVT_ROWS][e % GEMVT_ROWS] = V[(long long)(e / GEMVT_ROWS) * ldv + row0 + e % GEMVT_ROWS];
+    __syncthreads();
+    if (col >= np) return;
+    d2 acc[NRHS];
+#pragma unroll
+    for (int q = 0; q < NRHS; ++q) acc[q] = (d2){0.0, 0.0};
+    const double* ap = A + (long long)row0 * lda + col;
+#pragma unroll 8
+    for (int r = 0; r < GEMVT_ROWS; ++r) {
+        const d2 av = *(const d2*)(ap + (long long)r * lda);
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) acc[q] += av * vs[q][r];
+    }
+#pragma unroll
+    for (int q = 0; q < NRHS; ++q)
+        *(d2*)(Upart + ((long long)blockIdx.y * NRHS + q) * np + col) = acc[q];
+}
+
+__global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __restrict__ Upart, int nsplit,
+                                                            int nrhs, int np, double* __restrict__ U,
+                                                            long long ldu) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= np) return;
+    for (int q = 0; q < nrhs; ++q) {
+        double s = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) s += Upart[((long long)sp * nrhs + q) * np + k];
+        U[(long long)q * ldu + k] = s;
+    }
+}
+
+hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
+                         int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
+                         hipStream_t st) {
+    const int grid = (m + GN_ROWS_PER_WG - 1) / GN_ROWS_PER_WG;
+    if (nrhs == 1)
+        hipLaunchKernelGGL(gemv_n_kernel<1>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
+                           (long long)ldw, add0, add1, Y, (long long)ldy);
+    else
+        hipLaunchKernelGGL(gemv_n_kernel<2>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
+                           (long long)ldw, add0, add1, Y, (long long)ldy);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
+                         int64_t ldv, double* Upart, hipStream_t st) {
+    dim3 grid((np / 2 + 255) / 256, mp / GEMVT_ROWS);
+    if (nrhs == 1)
+        hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart);
+    else
+        hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemv_t_reduce(const double* Upart, int nsplit, int nrhs, int np, double* U, int64_t ldu,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3((np + 255) / 256), dim3(256), 0, st, Upart, nsplit, nrhs,
+                       np, U, (long long)ldu);
+    return hipGetLastError();
+}
+
+}  // namespace lpipm

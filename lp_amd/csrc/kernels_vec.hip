@@ -1,0 +1,387 @@
+// kernels_vec.hip -- the O(n) vector kernels and the one-wave scalar kernels of the IPM iteration.
+//
+// Everything the reference does between its GEMVs and solves (rhat.rs, delta.rs, the step-size
+// ratio test and step of feasible_point.rs, residual.rs, indicators.rs) runs here on device so an
+// iteration needs no host round trip: scalars (tau, kappa, mu, gamma, eta, d_tau, alpha, ...) live
+// in a device block `S`, reductions are two-stage (per-workgroup partials in `red`, summed in
+// fixed order by the next scalar kernel) and therefore bitwise reproducible.
+// Each kernel cites the reference lines whose arithmetic (and operation order) it reproduces.
+#include "vec_kernels.hpp"
+
+namespace lpipm {
+
+// ---------------------------------------------------------------- reduction helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// workgroup (256 threads) reduction of K values; thread 0 writes red[slot0 + k][blockIdx.x]
+template <int K, bool IS_MIN>
+__device__ __forceinline__ void block_reduce_store(double (&v)[K], double* red, int slot0) {
+    __shared__ double sm[4][K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double w = IS_MIN ? wave_min(v[k]) : wave_sum(v[k]);
+        if (lane == 0) sm[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double r = IS_MIN ? fmin(fmin(sm[0][k], sm[1][k]), fmin(sm[2][k], sm[3][k]))
+                                    : (sm[0][k] + sm[1][k]) + (sm[2][k] + sm[3][k]);
+            red[(slot0 + k) * RED_STRIDE + blockIdx.x] = r;
+        }
+    }
+}
+// one wave folds the nblk partials of a slot in a fixed order; every lane gets the result
+__device__ __forceinline__ double fold_sum(const double* red, int slot, int nblk) {
+    double s = 0.0;
+    for (int b = (int)(threadIdx.x & 63); b < nblk; b += 64) s += red[slot * RED_STRIDE + b];
+    return wave_sum(s);
+}
+__device__ __forceinline__ double fold_min(const double* red, int slot, int nblk, double init) {
+    double s = init;
+    for (int b = (int)(threadIdx.x & 63); b < nblk; b += 64) s = fmin(s, red[slot * RED_STRIDE + b]);
+    return wave_min(s);
+}
+
+// ---------------------------------------------------------------- FeasiblePoint::blind_start
+// feasible_point.rs:24-31: x = 1, y = 0, z = 1, tau = kappa = 1
+__global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
+    const int stride = gridDim.x * 256;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) { a.x[j] = 1.0; a.z[j] = 1.0; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.y[i] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.S[S_TAU] = 1.0;
+        a.S[S_KAPPA] = 1.0;
+        *a.flags = 0;
+    }
+}
+
+// ---------------------------------------------------------------- residuals at the current point
+// residual.rs:22-31 and feasible_point.rs:122-123 (the same vectors):
+//   r_P = b*tau - A.x            (Ax from gemv_n)
+//   r_D = c*tau - A^T.y - z      (A^T.y = sum of the gemv_t row-split slabs)
+// partial sums: |r_P|^2, b.y, |r_D|^2, c.x, x.z, c.(x/tau)   (indicators.rs:41-44)
+__global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
+    const int stride = gridDim.x * 256;
+    const double tau = a.S[S_TAU];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) {
+        const double r = a.b[i] * tau - a.Ax[i];
+        a.rP[i] = r;
+        acc[0] += r * r;
+        acc[1] += a.b[i] * a.y[i];
+    }
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        double aty = 0.0;
+        for (int s = 0; s < a.nsplit; ++s) aty += a.ATpart[(long long)s * a.np + j];
+        const double xj = a.x[j], zj = a.z[j], cj = a.c[j];
+        const double r = cj * tau - aty - zj;
+        a.rD[j] = r;
+        acc[2] += r * r;
+        acc[3] += cj * xj;
+        acc[4] += xj * zj;
+        acc[5] += cj * (xj / tau);
+    }
+    block_reduce_store<6, false>(acc, a.red, 0);
+}
+
+// Residuals::calculate + Indicators::from_point_and_problem + Indicators::status
+// (residual.rs:33-43, indicators.rs:37-55, :57-83), then the scalars the NEXT get_delta starts
+// from (feasible_point.rs:119-125, rhat.rs:31,33).
+__global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol, double c0) {
+    const int nblk = a.nblk;
+    const double rp2 = fold_sum(a.red, 0, nblk), by = fold_sum(a.red, 1, nblk);
+    const double rd2 = fold_sum(a.red, 2, nblk), cx = fold_sum(a.red, 3, nblk);
+    const double xz = fold_sum(a.red, 4, nblk), cxt = fold_sum(a.red, 5, nblk);
+    if (threadIdx.x != 0) return;
+    double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA];
+    const double rho_p = sqrt(rp2);                                   // residual.rs:34
+    const double rho_d = sqrt(rd2);                                   // residual.rs:35
+    const double rho_g = fabs(kappa + cx - by);                       // residual.rs:27-29,36
+    const double rho_mu = (xz + tau * kappa) / (double)(a.n + 1);     // residual.rs:30-32,37
+    if (is_init) {                                                    // feasible_point.rs:32
+        S[S_RP0] = rho_p; S[S_RD0] = rho_d; S[S_RG0] = rho_g; S[S_RMU0] = rho_mu;
+    }
+    StatusRec* st = a.status;
+    const double obj = cxt + c0;                                      // indicators.rs:41
+    const double bty = by;                                            // indicators.rs:42
+    const double rho_A = fabs(cx - bty) / (tau + fabs(by));           // indicators.rs:43-44
+    const double ip_ = rho_p / fmax(S[S_RP0], 1.0);                   // indicators.rs:47
+    const double id_ = rho_d / fmax(S[S_RD0], 1.0);                   // indicators.rs:48
+    const double ig_ = rho_g / fmax(S[S_RG0], 1.0);                   // indicators.rs:50
+    const double imu = rho_mu / S[S_RMU0];                            // indicators.rs:51
+    st->alpha = is_init ? 1.0 : S[S_ALPHA];
+    st->rho_p = ip_; st->rho_d = id_; st->rho_A = rho_A; st->rho_g = ig_; st->rho_mu = imu; st->obj = obj;
+    st->tau = tau; st->kappa = kappa;
+    int status = ST_UNFINISHED;
+    if (!is_init) {                                                   // indicators.rs:66-83
+        const bool tau_too_small = tau < tol * fmax(kappa, 1.0);
+        const bool inf1 = (ip_ < tol && id_ < tol && ig_ < tol) && tau_too_small;
+        const bool inf2 = imu < tol && tau_too_small;
+        if (inf1 || inf2) status = bty > tol ? ST_INFEASIBLE : ST_UNBOUNDED;
+        else if (ip_ < tol && id_ < tol && rho_A < tol) status = ST_OPTIMAL;
+    }
+    st->status = status;
+    st->potrf_info = *a.potrf_info;
+    st->flags = *a.flags;
+    // next get_delta (feasible_point.rs:119-125)
+    const double gamma = ip_next ? 1.0 : 0.0;
+    const double eta = ip_next ? 1.0 : 1.0 - gamma;
+    const double rG = cx - by + kappa;                                // :124
+    const double mu = (xz + tau * kappa) / (double)(a.n + 1);         // :125
+    S[S_RG] = rG; S[S_MU] = mu; S[S_GAMMA] = gamma; S[S_ETA] = eta;
+    S[S_RHAT_G] = rG * eta;                                           // rhat.rs:31
+    S[S_RHAT_TK] = gamma * mu - tau * kappa;                          // rhat.rs:33
+}
+
+// ---------------------------------------------------------------- predictor set-up
+// newton_equations.rs:54 (Dinv = x/z); rhat.rs:29-32 (predictor r_hat); the r1 argument of the
+// second sym_solve (newton_equations.rs:188: rhat.d - rhat.xs/x) and the Dinv*r1 prologues of both
+// sym_solve calls (:220).
+__global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
+    const int stride = gridDim.x * 256;
+    const double gm = a.S[S_GAMMA] * a.S[S_MU], eta = a.S[S_ETA];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        const double xj = a.x[j], zj = a.z[j];
+        const double dinv = xj / zj;
+        const double xs = (xj * -1.0) * zj + gm;
+        const double r1 = a.rD[j] * eta - xs / xj;
+        a.dinv[j] = dinv;
+        a.xs[j] = xs;
+        a.r1[j] = r1;
+        a.W[j] = dinv * a.c[j];
+        a.W[a.np + j] = dinv * r1;
+    }
+}
+
+// sym_solve epilogue u = Dinv*(A^T.v - r1) for both solves of the predictor
+// (newton_equations.rs:223), the four dots of delta.rs:29-32 and the NaN check of :190-194.
+__global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
+    const int stride = gridDim.x * 256;
+    double acc[4] = {0, 0, 0, 0};
+    int nan = 0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        double atq = 0.0, atv = 0.0;
+        for (int s = 0; s < a.nsplit; ++s) {
+            atq += a.ATpart[((long long)s * 2 + 0) * a.np + j];
+            atv += a.ATpart[((long long)s * 2 + 1) * a.np + j];
+        }
+        const double d = a.dinv[j], cj = a.c[j];
+        const double p = d * (atq - cj);
+        const double u = d * (atv - a.r1[j]);
+        a.p[j] = p;
+        a.u[j] = u;
+        acc[0] += cj * p;
+        acc[1] += cj * u;
+        nan |= (p != p);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) {
+        const double q = a.R[i], v = a.R[a.mp + i], bi = a.b[i];
+        a.q[i] = q;
+        acc[2] += bi * q;
+        acc[3] += bi * v;
+        nan |= (q != q);
+    }
+    if (nan) atomicOr(a.flags, FLAG_NAN_PQ);
+    block_reduce_store<4, false>(acc, a.red, 0);
+}
+
+// corrector: only (u, v) change; (p, q) are identical to the predictor's (the reference recomputes
+// them, feasible_point.rs:149 -> newton_equations.rs:187, with the same inputs and factor).
+__global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
+    const int stride = gridDim.x * 256;
+    double acc[2] = {0, 0};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        double atv = 0.0;
+        for (int s = 0; s < a.nsplit; ++s) atv += a.ATpart[(long long)s * a.np + j];
+        const double u = a.dinv[j] * (atv - a.r1[j]);
+        a.u[j] = u;
+        acc[0] += a.c[j] * u;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) acc[1] += a.b[i] * a.R[i];
+    block_reduce_store<2, false>(acc, a.red, 0);
+}
+
+// delta.rs:29-32 (d_tau) and :38 (d_kappa).  phase 0: predictor (all four dots fresh);
+// phase 1: corrector (c.p, b.q reused from the predictor).
+__global__ void k_scalar_dtau(VecArgs a, int phase) {
+    const int nblk = a.nblk;
+    double cp, cu, bq, bv;
+    if (phase == 0) {
+        cp = fold_sum(a.red, 0, nblk); cu = fold_sum(a.red, 1, nblk);
+        bq = fold_sum(a.red, 2, nblk); bv = fold_sum(a.red, 3, nblk);
+    } else {
+        cu = fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk);
+        cp = a.S[S_CP]; bq = a.S[S_BQ];
+    }
+    if (threadIdx.x != 0) return;
+    double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA];
+    const double d_tau = (S[S_RHAT_G] + 1.0 / tau * S[S_RHAT_TK] - (-cu + bv)) /
+                         (1.0 / tau * kappa + (-cp + bq));
+    const double d_kappa = 1.0 / tau * (S[S_RHAT_TK] - kappa * d_tau);
+    S[S_CP] = cp; S[S_BQ] = bq;
+    S[S_DTAU] = d_tau; S[S_DKAPPA] = d_kappa;
+}
+
+// delta.rs:33-37 + the folds of get_step_size (feasible_point.rs:54-62).
+// phase 0 keeps only d_x*d_z (all the corrector needs, rhat.rs:55,64); phase 1 keeps d_x, d_y, d_z.
+__global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
+    const int stride = gridDim.x * 256;
+    const double d_tau = a.S[S_DTAU];
+    double mn[2] = {1.0, 1.0};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        const double xj = a.x[j], zj = a.z[j];
+        const double dx = a.u[j] + a.p[j] * d_tau;
+        const double dz = (a.xs[j] - zj * dx) / xj;
+        if (dx < 0.0) mn[0] = fmin(mn[0], xj / -dx);
+        if (dz < 0.0) mn[1] = fmin(mn[1], zj / -dz);
+        if (phase == 0) a.dxdz[j] = dx * dz;
+        else { a.dx[j] = dx; a.dz[j] = dz; }
+    }
+    if (phase == 1)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride)
+            a.dy[i] = a.R[i] + a.q[i] * d_tau;
+    block_reduce_store<2, true>(mn, a.red, 0);
+}
+
+// get_step_size tail (feasible_point.rs:63-71).  phase 0: alpha of the predictor (alpha0 = 1),
+// update_gamma (:156-165), eta (:136) and the scalar parts of Rhat::corrector (rhat.rs:51-74).
+// phase 1: the step length of the iteration (interior_point/mod.rs:216-221).
+__global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
+    const int nblk = a.nblk;
+    const double ax = fold_min(a.red, 0, nblk, 1.0), az = fold_min(a.red, 1, nblk, 1.0);
+    if (threadIdx.x != 0) return;
+    double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA];
+    const double at = d_tau < 0.0 ? fmin(1.0, tau / -d_tau) : 1.0;
+    const double ak = d_kappa < 0.0 ? fmin(1.0, kappa / -d_kappa) : 1.0;
+    const double amin = fmin(fmin(fmin(fmin(1.0, ax), at), az), ak);
+    if (phase == 0) {
+        const double alpha = amin * 1.0;                              // feasible_point.rs:134
+        const double mu = S[S_MU];
+        double gamma;
+        if (ip) gamma = 10.0;                                         // :158-160
+        else gamma = (1.0 - alpha) * (1.0 - alpha) * fmin(0.1, 1.0 - alpha);  // :163-164
+        const double eta = ip ? 1.0 : 1.0 - gamma;                    // :136
+        double tk;
+        if (ip) {                                                     // rhat.rs:52,57-59
+            const double alpha_2 = alpha * alpha;
+            tk = (1.0 - alpha) * gamma * mu - tau * kappa - alpha_2 * d_tau * d_kappa;
+        } else {                                                      // rhat.rs:65
+            tk = gamma * mu - tau * kappa - d_tau * d_kappa;
+        }
+        S[S_ALPHA_PRED] = alpha; S[S_GAMMA] = gamma; S[S_ETA] = eta;
+        S[S_RHAT_G] = S[S_RG] * eta;                                  // rhat.rs:71
+        S[S_RHAT_TK] = tk;
+    } else {
+        S[S_ALPHA] = ip ? 1.0 : amin * alpha0;                        // mod.rs:216-221
+    }
+}
+
+// Rhat::corrector vector parts (rhat.rs:51-56 / :62-64, :69-70) and the r1 / Dinv*r1 of the
+// corrector's sym_solve (newton_equations.rs:188, :220).
+__global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
+    const int stride = gridDim.x * 256;
+    const double gamma = a.S[S_GAMMA], mu = a.S[S_MU], eta = a.S[S_ETA], alpha = a.S[S_ALPHA_PRED];
+    const double alpha_2 = alpha * alpha;
+    const double ipterm = (1.0 - alpha) * gamma * mu;
+    const double gm = gamma * mu;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        const double xj = a.x[j], zj = a.z[j], pr = a.dxdz[j];
+        double xs;
+        if (ip) xs = (xj * -1.0) * zj - pr * alpha_2 + ipterm;
+        else    xs = (xj * -1.0) * zj + gm - pr;
+        const double r1 = a.rD[j] * eta - xs / xj;
+        a.xs[j] = xs;
+        a.r1[j] = r1;
+        a.W[j] = a.dinv[j] * r1;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.rP2[i] = a.rP[i] * eta;
+}
+
+// FeasiblePoint::do_step (feasible_point.rs:76-106)
+__global__ __launch_bounds__(256) void k_step(VecArgs a, int ip) {
+    const int stride = gridDim.x * 256;
+    const double alpha = a.S[S_ALPHA];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        double xn = a.x[j] + a.dx[j] * alpha;
+        double zn = a.z[j] + a.dz[j] * alpha;
+        if (ip) { xn = fmax(xn, 1.0); zn = fmax(zn, 1.0); }
+        a.x[j] = xn;
+        a.z[j] = zn;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.y[i] = a.y[i] + a.dy[i] * alpha;
+}
+// tau / kappa part of do_step: separate one-thread launch so that no kernel both reads and writes S
+__global__ void k_step_scalars(VecArgs a, int ip) {
+    if (threadIdx.x != 0) return;
+    double* S = a.S;
+    const double alpha = S[S_ALPHA];
+    double tau = S[S_TAU] + S[S_DTAU] * alpha;
+    double kappa = S[S_KAPPA] + S[S_DKAPPA] * alpha;
+    if (ip) { tau = fmax(tau, 1.0); kappa = fmax(kappa, 1.0); }
+    S[S_TAU] = tau;
+    S[S_KAPPA] = kappa;
+}
+
+// x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
+__global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
+    const int stride = gridDim.x * 256;
+    const double tau = a.S[S_TAU];
+    double acc[1] = {0};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+        const double v = a.x[j] / tau;
+        xout[j] = v;
+        acc[0] += a.c[j] * v;
+    }
+    block_reduce_store<1, false>(acc, a.red, 0);
+}
+__global__ void k_scalar_fun(VecArgs a, double c0) {
+    const double s = fold_sum(a.red, 0, a.nblk);
+    if (threadIdx.x == 0) a.status->obj = s + c0;
+}
+
+// ---------------------------------------------------------------- launchers
+static inline dim3 vgrid(const VecArgs& a) { return dim3(a.nblk); }
+
+void vec_blind_start(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_blind_start, vgrid(a), dim3(256), 0, st, a); }
+void vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st) {
+    hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_scalar_indicators, dim3(1), dim3(64), 0, st, a, is_init, ip_next, tol, c0);
+}
+void vec_pred_setup(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_pred_setup, vgrid(a), dim3(256), 0, st, a); }
+void vec_pq_uv(const VecArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_pq_uv, vgrid(a), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 0);
+}
+void vec_uv_corr(const VecArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_uv_corr, vgrid(a), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 1);
+}
+void vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st) {
+    hipLaunchKernelGGL(k_delta, vgrid(a), dim3(256), 0, st, a, phase);
+    hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(64), 0, st, a, phase, ip, alpha0);
+}
+void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) { hipLaunchKernelGGL(k_corr_setup, vgrid(a), dim3(256), 0, st, a, ip); }
+void vec_step(const VecArgs& a, int ip, hipStream_t st) {
+    hipLaunchKernelGGL(k_step, vgrid(a), dim3(256), 0, st, a, ip);
+    hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(64), 0, st, a, ip);
+}
+void vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st) {
+    hipLaunchKernelGGL(k_final_x, vgrid(a), dim3(256), 0, st, a, xout);
+    hipLaunchKernelGGL(k_scalar_fun, dim3(1), dim3(64), 0, st, a, c0);
+}
+
+}  // namespace lpipm

@@ -1,0 +1,82 @@
+// lpipm_internal.hpp -- shared declarations of liblpipm.so (host C++ + HIP kernels for gfx950).
+// Product code: nothing here may include, link or call anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include "../../include/lpipm.h"
+
+namespace lpipm {
+
+// ---------------------------------------------------------------- geometry
+constexpr int TILE = 128;  // output tile edge of the MFMA NT-GEMM == Cholesky block size NB
+constexpr int BK   = 16;   // k-tile depth staged through LDS per barrier
+constexpr int NB   = 128;  // Cholesky / TRSV block size (== TILE)
+
+inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
+
+// ---------------------------------------------------------------- error plumbing
+void set_error_detail(const char* what, hipError_t e, const char* file, int line);
+#define LP_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) {                                            \
+            ::lpipm::set_error_detail(#expr, e__, __FILE__, __LINE__);      \
+            return LPIPM_ERR_HIP;                                           \
+        }                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------- NT GEMM (kernels_gemm.hip)
+// C(tile ti,tj) = beta*C + alpha * sum_k P[ti*128+r][k] * s[k] * Q[tj*128+c][k]
+// Row-major operands with K contiguous ("NT"): this one MFMA kernel serves
+//   A.D.A^T            (P = Q = A, s = x/z, lower tiles, stream-K over n)   newton_equations.rs:55-57
+//   trailing update    (P = Q = L21, alpha=-1, beta=1, lower tiles)         Cholesky, :129-131
+//   TRSM as GEMM       (P = A21, Q = inv(L11), rectangular tiles)
+struct GemmArgs {
+    const double* P; int64_t ldp;
+    const double* Q; int64_t ldq;
+    const double* s;            // nullable: per-k scale applied to the Q panel while staging
+    double*       C; int64_t ldc;
+    int           K;            // multiple of BK
+    double        alpha, beta;
+    int           ntiles;
+    int           tiles_lower;  // 1: tile index -> lower triangle (row-major), 0: rectangular
+    int           ntj;          // rectangular: number of tile columns
+    const int2*   tile_list;    // nullable: explicit (ti,tj) order (device pointer)
+    int           diag_pad_from;// rows/cols >= this on the diagonal are written as 1.0 (-1: off)
+    double*       ws;           // stream-K partial slabs: 2 per workgroup, TILE*TILE doubles each
+    int           nwg;          // workgroups launched (== grid); ntiles*KT split evenly
+};
+// Launches the main kernel and, when the k-range of a tile is split over workgroups, the
+// deterministic fix-up pass.  ws must hold 2*nwg slabs when nwg != ntiles.
+hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st);
+// Workgroup count the stream-K ADA^T launch wants for ntiles x KT work.
+int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
+
+// ---------------------------------------------------------------- Cholesky (kernels_potrf.hip)
+// In-place blocked lower Cholesky of the mp x mp row-major matrix M (mp multiple of NB).
+// invL receives the inverse of every NB x NB diagonal block of L (mp/NB slabs, row-major).
+// info (device int32): 0, or 1 + index of the first non-positive pivot.
+hipError_t launch_potrf(double* M, int64_t ld, int mp, double* invL, int32_t* info, hipStream_t st);
+
+// ---------------------------------------------------------------- triangular solves (kernels_trsv.hip)
+// In place: R[r] <- L^-T L^-1 R[r], r < nrhs (1|2); R is nrhs x mp (row stride mp).
+// (solve launcher with workspace: vec_kernels.hpp, launch_chol_solve_ws)
+
+// ---------------------------------------------------------------- GEMV (kernels_gemv.hip)
+// Y[r][i] = (add[r] ? add[r][i] : 0) + sum_k A[i][k] * W[r][k],   i < m (rows of the padded A)
+hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
+                         int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
+                         hipStream_t st);
+// Upart[s][r][k] = sum_{i in row split s} A[i][k] * V[r][i];  consumers sum the splits in order.
+constexpr int GEMVT_ROWS = 128;
+hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
+                         int64_t ldv, double* Upart, hipStream_t st);
+// U[r][k] = sum_s Upart[s][r][k]   (stand-alone reduce; the solver fuses this into its consumers)
+hipError_t launch_gemv_t_reduce(const double* Upart, int nsplit, int nrhs, int np, double* U,
+                                int64_t ldu, hipStream_t st);
+
+// ---------------------------------------------------------------- probe (kernels_probe.hip)
+hipError_t launch_mfma_probe(int iters, double* sink, int blocks, hipStream_t st);
+
+}  // namespace lpipm

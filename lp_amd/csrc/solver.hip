@@ -1,0 +1,622 @@
+// solver.hip -- the device-resident interior-point loop behind the C ABI (include/lpipm.h).
+//
+// Host side of InteriorPoint::solve_normal_form (interior_point/mod.rs:199-240): A is uploaded
+// once; every iteration is a fixed sequence of kernel launches on the ctx's stream with all
+// scalars on device; the host reads back one 96-byte status record per iteration to decide
+// termination exactly as mod.rs:230-235 does.  There is no CPU fallback: every numerical step is
+// a HIP kernel, and a missing/unusable device is an error.
+//
+// Algebraic reuse that leaves results identical to the reference (same inputs, same arithmetic):
+//   * (p, q) = sym_solve(c, b) is computed once per iteration; the reference recomputes it for the
+//     corrector with the same factor and inputs (feasible_point.rs:149 -> newton_equations.rs:187);
+//   * r_P, r_D of the next get_delta (feasible_point.rs:122-123) are the vectors whose norms the
+//     indicators just took (residual.rs:22-26) at the same point;
+//   * the predictor's two sym_solve calls share one pass over A per GEMV and one 2-RHS solve.
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "vec_kernels.hpp"
+
+using namespace lpipm;
+
+namespace lpipm {
+static thread_local std::string g_err_detail;
+void set_error_detail(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s -> %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err_detail = buf;
+}
+}  // namespace lpipm
+
+enum { T_VEC = 0, T_ADAT, T_POTRF, T_TRSV, T_GEMV, T_NTAGS };
+
+struct lpipm_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    int num_cu = 256;
+    bool has_problem = false;
+    uint64_t m = 0, n = 0;
+    int mp = 0, np = 0, nblk = 1, nsplit = 1;
+    double c0 = 0.0;
+    std::vector<void*> allocs;   // problem-sized device buffers
+    std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
+    // problem + state + work
+    double *A = nullptr, *M = nullptr, *invL = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
+    int2* tile_list = nullptr;
+    int ntiles = 0, adat_nwg = 1;
+    VecArgs va{};
+    StatusRec* status_host = nullptr;  // pinned
+    // stand-alone potrf/solve buffers
+    double *kM = nullptr, *kM0 = nullptr, *kinvL = nullptr, *kR = nullptr, *kY = nullptr;
+    int32_t* kinfo = nullptr;
+    int kmp = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    std::vector<int> mark_tags;
+    size_t nmarks = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    double tag_ms[T_NTAGS] = {0, 0, 0, 0, 0};
+    lpipm_phase_times times{};
+};
+
+// ------------------------------------------------------------------------------------------------
+static int free_list(std::vector<void*>& v) {
+    for (void* p : v) (void)hipFree(p);
+    v.clear();
+    return 0;
+}
+template <typename T>
+static int dalloc(std::vector<void*>& list, T** out, size_t count, hipStream_t st) {
+    void* p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    LP_HIP(hipMalloc(&p, bytes));
+    list.push_back(p);
+    LP_HIP(hipMemsetAsync(p, 0, bytes, st));
+    *out = (T*)p;
+    return LPIPM_OK;
+}
+#define LP_TRY(expr) do { int rc__ = (expr); if (rc__ != LPIPM_OK) return rc__; } while (0)
+
+static void prof_mark(lpipm_ctx* c, int tag) {
+    if (!c->profiling) return;
+    if (c->nmarks == c->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->events.push_back(e);
+        c->mark_tags.push_back(0);
+    }
+    c->mark_tags[c->nmarks] = tag;
+    (void)hipEventRecord(c->events[c->nmarks], c->st);
+    ++c->nmarks;
+}
+// call after the stream has been synchronised
+static void prof_collect(lpipm_ctx* c) {
+    if (!c->profiling) return;
+    for (size_t i = 1; i < c->nmarks; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->events[i - 1], c->events[i]) == hipSuccess)
+            c->tag_ms[c->mark_tags[i]] += ms;
+    }
+    c->nmarks = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" void lpipm_default_opts(lpipm_opts* o) {  // interior_point/mod.rs:50-60
+    if (!o) return;
+    o->tol = 1e-8; o->alpha0 = 0.99995; o->max_iter = 1000; o->ip = 1;
+    o->solver_type = LPIPM_SOLVER_CHOLESKY; o->disp = 0;
+}
+
+extern "C" const char* lpipm_strerror(int s) {  // error.rs:10-28
+    switch (s) {
+        case LPIPM_OK: return "Ok";
+        case LPIPM_UNCONSTRAINED:
+            return "The problem is unconstrained, meaning the solution is the all-zeros vector if `c` is nonnegative, or unbounded otherwise.";
+        case LPIPM_NUMERICAL_PROBLEM:
+            return "The solver encountered numerical problems it could not recover from. Likely causes are linearly dependent constraints or variables whose scale differs by multiple orders of magnitude.";
+        case LPIPM_INVALID_PARAMETER: return "A parameter was set to an invalid value";
+        case LPIPM_INCOMPATIBLE_DIMENSIONS: return "The dimensions of your cost- and constraint arrays do not align.";
+        case LPIPM_INFEASIBLE: return "The solver finished successfully, it appears that the problem is infeasible.";
+        case LPIPM_UNBOUNDED: return "The solver finished successfully, it appears that your problem is unbounded.";
+        case LPIPM_ITERATION_LIMIT:
+            return "The solver failed to converge within the maximum number of iterations.";
+        case LPIPM_ERR_HIP: return "HIP runtime error (see lpipm_last_error_detail)";
+        case LPIPM_ERR_NO_PROBLEM: return "no problem uploaded on this context";
+        case LPIPM_ERR_UNSUPPORTED: return "not supported by the HIP backend yet";
+        case LPIPM_ERR_BAD_ARGUMENT: return "bad argument";
+        default: return "unknown status";
+    }
+}
+extern "C" const char* lpipm_last_error_detail(void) { return g_err_detail.c_str(); }
+
+extern "C" int lpipm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// linear_program.rs:125-169
+extern "C" int lpipm_problem_build(uint64_t n, uint64_t m_ub, const double* A_ub, const double* b_ub,
+                                   uint64_t m_eq, const double* A_eq, const double* b_eq, const double* c,
+                                   double* A_out, double* b_out, double* c_out, uint64_t* n_slack_out) {
+    if (m_ub + m_eq == 0) return LPIPM_UNCONSTRAINED;                       // :134-136
+    if (!c || !A_out || !b_out || !c_out || !n_slack_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if ((m_ub && (!A_ub || !b_ub)) || (m_eq && (!A_eq || !b_eq))) return LPIPM_ERR_BAD_ARGUMENT;
+    const uint64_t m = m_ub + m_eq, ns = n + m_ub;
+    for (uint64_t i = 0; i < m; ++i) {                                       // :145-156
+        const double* src = i < m_ub ? A_ub + i * n : A_eq + (i - m_ub) * n;
+        double* dst = A_out + i * ns;
+        for (uint64_t j = 0; j < n; ++j) dst[j] = src[j];
+        for (uint64_t j = 0; j < m_ub; ++j) dst[n + j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (uint64_t i = 0; i < m; ++i) b_out[i] = i < m_ub ? b_ub[i] : b_eq[i - m_ub];  // :157-158
+    for (uint64_t j = 0; j < ns; ++j) c_out[j] = j < n ? c[j] : 0.0;                  // :159-160
+    *n_slack_out = m_ub;                                                               // :161
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_create(int device, lpipm_ctx** out) {
+    if (!out) return LPIPM_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    LP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        g_err_detail = "device index out of range (no usable HIP device?)";
+        return LPIPM_ERR_HIP;
+    }
+    LP_HIP(hipSetDevice(device));
+    lpipm_ctx* c = new lpipm_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->status_host, sizeof(StatusRec)) != hipSuccess ||
+        hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+        g_err_detail = "failed to create stream / pinned status / events";
+        delete c;
+        return LPIPM_ERR_HIP;
+    }
+    *out = c;
+    return LPIPM_OK;
+}
+
+extern "C" void lpipm_destroy(lpipm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    free_list(c->allocs);
+    free_list(c->kallocs);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+    if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+// Order in which the lower-triangular 128x128 tiles of M are handed to workgroups: 8x8 super-blocks
+// (row-major over the lower triangle of super-blocks, row-major inside), so the ~64 workgroups that
+// share an XCD's L2 read 16 row panels of A for 64 tiles.
+static std::vector<int2> adat_tile_order(int nt) {
+    std::vector<int2> v;
+    v.reserve((size_t)nt * (nt + 1) / 2);
+    const int ns = (nt + 7) / 8;
+    for (int SI = 0; SI < ns; ++SI)
+        for (int SJ = 0; SJ <= SI; ++SJ)
+            for (int ti = SI * 8; ti < nt && ti < SI * 8 + 8; ++ti)
+                for (int tj = SJ * 8; tj < SJ * 8 + 8 && tj <= ti; ++tj) v.push_back(make_int2(ti, tj));
+    return v;
+}
+
+extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
+                            const double* b, const double* cc, double c0) {
+    if (!c || !A || !b || !cc || lda < n) return LPIPM_ERR_BAD_ARGUMENT;
+    if (m == 0) return LPIPM_UNCONSTRAINED;  // linear_program.rs:134-136
+    if (n == 0 || m > (1u << 20) || n > (1u << 24)) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipSetDevice(c->device));
+    const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK);
+    if (!c->has_problem || mp != c->mp || np != c->np) {
+        LP_HIP(hipStreamSynchronize(c->st));
+        free_list(c->allocs);
+        c->has_problem = false;
+        c->mp = mp; c->np = np;
+        c->nsplit = mp / GEMVT_ROWS;
+        const uint64_t big = m > n ? m : n;
+        c->nblk = (int)((big + 255) / 256);
+        if (c->nblk > RED_STRIDE) c->nblk = RED_STRIDE;
+        VecArgs& v = c->va;
+        auto& L = c->allocs;
+        hipStream_t st = c->st;
+        LP_TRY(dalloc(L, &c->A, (size_t)mp * np, st));
+        double *bb, *ccv;
+        LP_TRY(dalloc(L, &bb, (size_t)mp, st)); LP_TRY(dalloc(L, &ccv, (size_t)np, st));
+        v.b = bb; v.c = ccv;
+        LP_TRY(dalloc(L, &v.x, (size_t)np, st)); LP_TRY(dalloc(L, &v.y, (size_t)mp, st)); LP_TRY(dalloc(L, &v.z, (size_t)np, st));
+        LP_TRY(dalloc(L, &v.dinv, (size_t)np, st)); LP_TRY(dalloc(L, &v.xs, (size_t)np, st)); LP_TRY(dalloc(L, &v.r1, (size_t)np, st));
+        LP_TRY(dalloc(L, &v.rD, (size_t)np, st)); LP_TRY(dalloc(L, &v.p, (size_t)np, st)); LP_TRY(dalloc(L, &v.u, (size_t)np, st));
+        LP_TRY(dalloc(L, &v.dx, (size_t)np, st)); LP_TRY(dalloc(L, &v.dz, (size_t)np, st)); LP_TRY(dalloc(L, &v.dxdz, (size_t)np, st));
+        LP_TRY(dalloc(L, &v.rP, (size_t)mp, st)); LP_TRY(dalloc(L, &v.rP2, (size_t)mp, st)); LP_TRY(dalloc(L, &v.q, (size_t)mp, st));
+        LP_TRY(dalloc(L, &v.dy, (size_t)mp, st)); LP_TRY(dalloc(L, &v.Ax, (size_t)mp, st));
+        LP_TRY(dalloc(L, &v.W, (size_t)2 * np, st)); LP_TRY(dalloc(L, &v.R, (size_t)2 * mp, st));
+        LP_TRY(dalloc(L, &c->Y, (size_t)2 * mp, st));
+        LP_TRY(dalloc(L, &c->ATpart, (size_t)c->nsplit * 2 * np, st));
+        v.ATpart = c->ATpart;
+        LP_TRY(dalloc(L, &v.S, (size_t)64, st)); LP_TRY(dalloc(L, &v.red, (size_t)RED_SLOTS * RED_STRIDE, st));
+        LP_TRY(dalloc(L, &v.status, 1, st));
+        LP_TRY(dalloc(L, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &v.flags, 1, st));
+        LP_TRY(dalloc(L, &c->M, (size_t)mp * mp, st));
+        LP_TRY(dalloc(L, &c->invL, (size_t)(mp / NB) * NB * NB, st));
+        LP_TRY(dalloc(L, &c->xout, (size_t)np, st));
+        const int nt = mp / TILE;
+        std::vector<int2> order = adat_tile_order(nt);
+        c->ntiles = (int)order.size();
+        c->adat_nwg = gemm_streamk_nwg(c->ntiles, np / BK, c->num_cu);
+        LP_TRY(dalloc(L, &c->tile_list, order.size(), st));
+        LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        LP_TRY(dalloc(L, &c->ws, (size_t)2 * c->adat_nwg * TILE * TILE, st));
+        LP_HIP(hipStreamSynchronize(st));  // `order` must outlive the copy
+        v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
+    } else {
+        LP_HIP(hipMemsetAsync(c->A, 0, (size_t)mp * np * sizeof(double), c->st));
+        LP_HIP(hipMemsetAsync((void*)c->va.b, 0, (size_t)mp * sizeof(double), c->st));
+        LP_HIP(hipMemsetAsync((void*)c->va.c, 0, (size_t)np * sizeof(double), c->st));
+    }
+    c->m = m; c->n = n; c->c0 = c0;
+    c->va.n = (int)n; c->va.m = (int)m;
+    LP_HIP(hipMemcpy2DAsync(c->A, (size_t)np * sizeof(double), A, (size_t)lda * sizeof(double),
+                            (size_t)n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpyAsync((void*)c->va.b, b, m * sizeof(double), hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpyAsync((void*)c->va.c, cc, n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    c->has_problem = true;
+    return LPIPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// M = A . diag(dinv) . A^T, lower tiles (newton_equations.rs:54-57)
+static hipError_t run_adat(lpipm_ctx* c) {
+    GemmArgs g{};
+    g.P = c->A; g.ldp = c->np; g.Q = c->A; g.ldq = c->np; g.s = c->va.dinv;
+    g.C = c->M; g.ldc = c->mp; g.K = c->np; g.alpha = 1.0; g.beta = 0.0;
+    g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
+    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg;
+    return launch_gemm_nt(g, c->st);
+}
+
+static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol) {
+    VecArgs& v = c->va;
+    // A.x and A^T.y at the current point (residual.rs:23,25)
+    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 1, v.x, c->np, nullptr, nullptr, v.Ax, c->mp, c->st));
+    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 1, v.y, c->mp, c->ATpart, c->st));
+    prof_mark(c, T_GEMV);
+    vec_residuals(v, is_init, ip_next, tol, c->c0, c->st);
+    LP_HIP(hipGetLastError());
+    return LPIPM_OK;
+}
+
+// one IPM iteration: get_delta (feasible_point.rs:110-152), step length (mod.rs:216-221),
+// do_step (:222), indicators (:225)
+static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
+    VecArgs& v = c->va;
+    hipStream_t st = c->st;
+    prof_mark(c, T_VEC);
+    vec_pred_setup(v, st);
+    prof_mark(c, T_VEC);
+    LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
+    prof_mark(c, T_ADAT);
+    LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->invL, v.potrf_info, st));   // :129-131
+    prof_mark(c, T_POTRF);
+    // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
+    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 2, v.W, c->np, v.b, v.rP, v.R, c->mp, st));  // :220
+    prof_mark(c, T_GEMV);
+    LP_HIP(launch_chol_solve_ws(c->M, c->mp, c->invL, c->mp, 2, v.R, c->Y, st));                     // :221
+    prof_mark(c, T_TRSV);
+    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 2, v.R, c->mp, c->ATpart, st));                  // :223
+    prof_mark(c, T_GEMV);
+    vec_pq_uv(v, st);                       // :223, delta.rs:29-32,38
+    vec_delta(v, 0, ip, 1.0, st);           // delta.rs:33-37, feasible_point.rs:134-136
+    vec_corr_setup(v, ip, st);              // rhat.rs:37-75
+    prof_mark(c, T_VEC);
+    // corrector: only the second sym_solve changes
+    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 1, v.W, c->np, v.rP2, nullptr, v.R, c->mp, st));
+    prof_mark(c, T_GEMV);
+    LP_HIP(launch_chol_solve_ws(c->M, c->mp, c->invL, c->mp, 1, v.R, c->Y, st));
+    prof_mark(c, T_TRSV);
+    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 1, v.R, c->mp, c->ATpart, st));
+    prof_mark(c, T_GEMV);
+    vec_uv_corr(v, st);
+    vec_delta(v, 1, ip, o->alpha0, st);     // mod.rs:216-221
+    vec_step(v, ip, st);                    // feasible_point.rs:76-106
+    prof_mark(c, T_VEC);
+    LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
+    LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+    prof_mark(c, T_VEC);
+    return LPIPM_OK;
+}
+
+static void print_row(double alpha, const StatusRec& s) {  // mod.rs:228 + indicators.rs:25-33
+    printf("%.8f\t%.8f\t%.8f\t%.8f\t%.8f\t%8.3f\n", alpha, s.rho_p, s.rho_d, s.rho_g, s.rho_mu, s.obj);
+}
+
+static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x_dev, double* fun_out,
+                      uint64_t* iters_out, lpipm_iter_row* log) {
+    if (!c || !o) return LPIPM_ERR_BAD_ARGUMENT;
+    // InteriorPointBuilder::build, mod.rs:118-128
+    if (!(o->alpha0 > 0.0) || !(o->alpha0 < 1.0)) return LPIPM_INVALID_PARAMETER;
+    if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
+    if (o->solver_type < 0 || o->solver_type > 2) return LPIPM_INVALID_PARAMETER;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    if (o->solver_type != LPIPM_SOLVER_CHOLESKY) return LPIPM_ERR_UNSUPPORTED;  // DESIGN.md, SURVEY 8(f)1
+    LP_HIP(hipSetDevice(c->device));
+    VecArgs& v = c->va;
+    hipStream_t st = c->st;
+    for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
+    c->times = lpipm_phase_times{};
+    c->nmarks = 0;
+    uint64_t adat_launches = 0;
+    if (c->profiling) LP_HIP(hipEventRecord(c->ev_begin, st));
+
+    vec_blind_start(v, st);                               // feasible_point.rs:24-31
+    prof_mark(c, T_VEC);
+    LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));  // feasible_point.rs:32, mod.rs:206
+    LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+    prof_mark(c, T_VEC);
+    LP_HIP(hipStreamSynchronize(st));
+    prof_collect(c);
+    if (o->disp) {                                        // mod.rs:208-211
+        printf("alpha     \trho_p     \trho_d     \trho_g     \trho_mu    \tobj       \n");
+        print_row(1.0, *c->status_host);
+    }
+    int ip = o->ip ? 1 : 0;
+    int ret = LPIPM_ITERATION_LIMIT;
+    uint64_t iteration = 0;
+    for (iteration = 1; iteration <= o->max_iter; ++iteration) {   // mod.rs:213
+        LP_TRY(enqueue_iteration(c, ip, o));
+        ++adat_launches;
+        LP_HIP(hipStreamSynchronize(st));
+        prof_collect(c);
+        const StatusRec s = *c->status_host;
+        // EquationSolverType::build failure (newton_equations.rs:58-63) and the NaN check on p, q
+        // (:190-194) both surface as NumericalProblem from get_delta (mod.rs:215)
+        if (s.potrf_info != 0 || (s.flags & FLAG_NAN_PQ)) { ret = LPIPM_NUMERICAL_PROBLEM; break; }
+        ip = 0;                                                    // mod.rs:223
+        if (o->disp) print_row(s.alpha, s);
+        if (log) {
+            lpipm_iter_row& r = log[iteration - 1];
+            r.alpha = s.alpha; r.rho_p = s.rho_p; r.rho_d = s.rho_d; r.rho_A = s.rho_A;
+            r.rho_g = s.rho_g; r.rho_mu = s.rho_mu; r.obj = s.obj;
+        }
+        if (s.status == ST_OPTIMAL) { ret = LPIPM_OK; break; }             // mod.rs:231
+        if (s.status == ST_INFEASIBLE) { ret = LPIPM_INFEASIBLE; break; }   // :232
+        if (s.status == ST_UNBOUNDED) { ret = LPIPM_UNBOUNDED; break; }     // :233
+    }
+    if (ret == LPIPM_ITERATION_LIMIT) iteration = o->max_iter;
+    if (ret == LPIPM_OK || ret == LPIPM_ITERATION_LIMIT) {
+        vec_final_x(v, c->xout, c->c0, st);                        // mod.rs:231/238, :165
+        LP_HIP(hipGetLastError());
+        if (x_dev) LP_HIP(hipMemcpyAsync(x_dev, c->xout, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (x_host) LP_HIP(hipMemcpyAsync(x_host, c->xout, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+        if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
+        LP_HIP(hipStreamSynchronize(st));
+        if (fun_out) *fun_out = c->status_host->obj;
+    } else {
+        if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
+        LP_HIP(hipStreamSynchronize(st));
+    }
+    if (iters_out) *iters_out = iteration;
+    if (c->profiling) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev_begin, c->ev_end);
+        c->times.total_ms = ms;
+        c->times.adat_ms = c->tag_ms[T_ADAT]; c->times.potrf_ms = c->tag_ms[T_POTRF];
+        c->times.trsv_ms = c->tag_ms[T_TRSV]; c->times.gemv_ms = c->tag_ms[T_GEMV];
+        c->times.vec_ms = c->tag_ms[T_VEC];
+        c->times.adat_launches = adat_launches; c->times.iterations = iteration;
+    }
+    return ret;
+}
+
+extern "C" int lpipm_solve(lpipm_ctx* c, const lpipm_opts* o, double* x_slack_out, double* fun_out,
+                           uint64_t* iterations_out, lpipm_iter_row* log) {
+    if (!x_slack_out) return LPIPM_ERR_BAD_ARGUMENT;
+    return solve_impl(c, o, x_slack_out, nullptr, fun_out, iterations_out, log);
+}
+extern "C" int lpipm_solve_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev_out, double* fun_out,
+                                  uint64_t* iterations_out, lpipm_iter_row* log) {
+    return solve_impl(c, o, nullptr, x_dev_out, fun_out, iterations_out, log);
+}
+
+extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
+                                 const double* const* A, const double* const* b, const double* const* cc,
+                                 const double* c0, const lpipm_opts* o, double* const* x_slack_out,
+                                 double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
+    if (!c || !o || (count && (!m || !n || !A || !b || !cc || !x_slack_out || !status_out)))
+        return LPIPM_ERR_BAD_ARGUMENT;
+    for (uint64_t i = 0; i < count; ++i) {
+        int rc = lpipm_upload(c, m[i], n[i], A[i], n[i], b[i], cc[i], c0 ? c0[i] : 0.0);
+        double fun = NAN;
+        uint64_t it = 0;
+        if (rc == LPIPM_OK) rc = lpipm_solve(c, o, x_slack_out[i], &fun, &it, nullptr);
+        status_out[i] = rc;
+        if (fun_out) fun_out[i] = fun;
+        if (iterations_out) iterations_out[i] = it;
+        if (rc >= 100) return rc;
+    }
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_set_profiling(lpipm_ctx* c, int on) {
+    if (!c) return LPIPM_ERR_BAD_ARGUMENT;
+    c->profiling = on != 0;
+    return LPIPM_OK;
+}
+extern "C" int lpipm_get_phase_times(const lpipm_ctx* c, lpipm_phase_times* out) {
+    if (!c || !out) return LPIPM_ERR_BAD_ARGUMENT;
+    *out = c->times;
+    return LPIPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-granularity entry points (parity tests / micro-benchmarks)
+template <typename F>
+static int timed_repeats(lpipm_ctx* c, int repeats, double* ms_out, F&& body) {
+    if (repeats < 1) repeats = 1;
+    float total = 0.f;
+    for (int r = 0; r < repeats; ++r) {
+        LP_HIP(hipEventRecord(c->ev_begin, c->st));
+        LP_TRY(body());
+        LP_HIP(hipEventRecord(c->ev_end, c->st));
+        LP_HIP(hipStreamSynchronize(c->st));
+        float ms = 0.f;
+        LP_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        total += ms;
+    }
+    if (ms_out) *ms_out = total / repeats;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_adat(lpipm_ctx* c, const double* dinv, double* M_out, int repeats, double* ms_out) {
+    if (!c || !dinv || !M_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    LP_HIP(hipSetDevice(c->device));
+    LP_HIP(hipMemcpyAsync(c->va.dinv, dinv, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int { LP_HIP(run_adat(c)); return LPIPM_OK; }));
+    LP_HIP(hipMemcpy2DAsync(M_out, c->m * sizeof(double), c->M, (size_t)c->mp * sizeof(double),
+                            c->m * sizeof(double), c->m, hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+static int kbuf_ensure(lpipm_ctx* c, int mp) {
+    if (c->kmp == mp) return LPIPM_OK;
+    LP_HIP(hipStreamSynchronize(c->st));
+    free_list(c->kallocs);
+    c->kmp = 0;
+    LP_TRY(dalloc(c->kallocs, &c->kM, (size_t)mp * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, &c->kM0, (size_t)mp * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, &c->kinvL, (size_t)(mp / NB) * NB * NB, c->st));
+    LP_TRY(dalloc(c->kallocs, &c->kR, (size_t)2 * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, &c->kY, (size_t)2 * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, &c->kinfo, 1, c->st));
+    c->kmp = mp;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t* info_out, int repeats,
+                             double* ms_out) {
+    if (!c || !M_inout || m == 0 || m > (1u << 20)) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipSetDevice(c->device));
+    const int mp = (int)round_up(m, NB);
+    LP_TRY(kbuf_ensure(c, mp));
+    // padded pristine copy: [[M, 0], [0, I]]
+    std::vector<double> pad((size_t)(mp - m), 1.0);
+    LP_HIP(hipMemsetAsync(c->kM0, 0, (size_t)mp * mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpy2DAsync(c->kM0, (size_t)mp * sizeof(double), M_inout, m * sizeof(double), m * sizeof(double),
+                            m, hipMemcpyHostToDevice, c->st));
+    if (mp > (int)m)
+        LP_HIP(hipMemcpy2DAsync(c->kM0 + m * mp + m, (size_t)(mp + 1) * sizeof(double), pad.data(), sizeof(double),
+                                sizeof(double), mp - m, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    if (repeats < 1) repeats = 1;
+    float total = 0.f;
+    for (int r = 0; r < repeats; ++r) {
+        LP_HIP(hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        LP_HIP(hipEventRecord(c->ev_begin, c->st));
+        LP_HIP(launch_potrf(c->kM, mp, mp, c->kinvL, c->kinfo, c->st));
+        LP_HIP(hipEventRecord(c->ev_end, c->st));
+        LP_HIP(hipStreamSynchronize(c->st));
+        float ms = 0.f;
+        LP_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        total += ms;
+    }
+    if (ms_out) *ms_out = total / repeats;
+    int32_t info = 0;
+    LP_HIP(hipMemcpyAsync(&info, c->kinfo, sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipMemcpy2DAsync(M_inout, m * sizeof(double), c->kM, (size_t)mp * sizeof(double), m * sizeof(double), m,
+                            hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    if (info_out) *info_out = info;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const double* R, double* V, int repeats,
+                                  double* ms_out) {
+    if (!c || !R || !V || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    const int mp = (int)round_up(m, NB);
+    if (c->kmp != mp) return LPIPM_ERR_NO_PROBLEM;  // needs a preceding lpipm_k_potrf of this size
+    LP_HIP(hipSetDevice(c->device));
+    if (repeats < 1) repeats = 1;
+    float total = 0.f;
+    for (int r = 0; r < repeats; ++r) {
+        LP_HIP(hipMemsetAsync(c->kR, 0, (size_t)2 * mp * sizeof(double), c->st));
+        LP_HIP(hipMemcpy2DAsync(c->kR, (size_t)mp * sizeof(double), R, m * sizeof(double), m * sizeof(double), nrhs,
+                                hipMemcpyHostToDevice, c->st));
+        LP_HIP(hipEventRecord(c->ev_begin, c->st));
+        LP_HIP(launch_chol_solve_ws(c->kM, mp, c->kinvL, mp, nrhs, c->kR, c->kY, c->st));
+        LP_HIP(hipEventRecord(c->ev_end, c->st));
+        LP_HIP(hipStreamSynchronize(c->st));
+        float ms = 0.f;
+        LP_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+        total += ms;
+    }
+    if (ms_out) *ms_out = total / repeats;
+    LP_HIP(hipMemcpy2DAsync(V, m * sizeof(double), c->kR, (size_t)mp * sizeof(double), m * sizeof(double), nrhs,
+                            hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_gemv_n(lpipm_ctx* c, int nrhs, const double* W, double* Y, int repeats, double* ms_out) {
+    if (!c || !W || !Y || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    LP_HIP(hipSetDevice(c->device));
+    LP_HIP(hipMemcpy2DAsync(c->va.W, (size_t)c->np * sizeof(double), W, c->n * sizeof(double), c->n * sizeof(double),
+                            nrhs, hipMemcpyHostToDevice, c->st));
+    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
+        LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, nrhs, c->va.W, c->np, nullptr, nullptr, c->va.R, c->mp, c->st));
+        return LPIPM_OK;
+    }));
+    LP_HIP(hipMemcpy2DAsync(Y, c->m * sizeof(double), c->va.R, (size_t)c->mp * sizeof(double), c->m * sizeof(double),
+                            nrhs, hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_gemv_t(lpipm_ctx* c, int nrhs, const double* V, double* U, int repeats, double* ms_out) {
+    if (!c || !V || !U || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    LP_HIP(hipSetDevice(c->device));
+    LP_HIP(hipMemsetAsync(c->va.R, 0, (size_t)2 * c->mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpy2DAsync(c->va.R, (size_t)c->mp * sizeof(double), V, c->m * sizeof(double), c->m * sizeof(double),
+                            nrhs, hipMemcpyHostToDevice, c->st));
+    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
+        LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, nrhs, c->va.R, c->mp, c->ATpart, c->st));
+        LP_HIP(launch_gemv_t_reduce(c->ATpart, c->nsplit, nrhs, c->np, c->va.W, c->np, c->st));
+        return LPIPM_OK;
+    }));
+    LP_HIP(hipMemcpy2DAsync(U, c->n * sizeof(double), c->va.W, (size_t)c->np * sizeof(double), c->n * sizeof(double),
+                            nrhs, hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_mfma_f64_probe(lpipm_ctx* c, int iters, double* tflops_out, double* ms_out) {
+    if (!c || iters < 1) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipSetDevice(c->device));
+    const int blocks = c->num_cu * 2;
+    double* sink = nullptr;
+    LP_HIP(hipMalloc((void**)&sink, (size_t)blocks * 256 * sizeof(double)));
+    double ms = 0.0;
+    int rc = timed_repeats(c, 3, &ms, [&]() -> int { LP_HIP(launch_mfma_probe(iters, sink, blocks, c->st)); return LPIPM_OK; });
+    (void)hipFree(sink);
+    if (rc != LPIPM_OK) return rc;
+    // per wave and loop trip: 16 independent accumulators x one 16x16x4 MFMA = 16 * 2048 flop
+    const double flop = (double)blocks * 4.0 * (double)iters * 16.0 * 2048.0;
+    if (ms_out) *ms_out = ms;
+    if (tflops_out) *tflops_out = flop / (ms * 1e-3) / 1e12;
+    return LPIPM_OK;
+}

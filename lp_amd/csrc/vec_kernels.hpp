@@ -1,0 +1,55 @@
+// vec_kernels.hpp -- argument block, scalar-slot indices and launchers of kernels_vec.hip.
+#pragma once
+#include "lpipm_internal.hpp"
+
+namespace lpipm {
+
+constexpr int RED_STRIDE = 512;  // max workgroups of a vector kernel == partials per reduction slot
+constexpr int RED_SLOTS  = 8;
+
+// device scalar block S
+enum {
+    S_TAU = 0, S_KAPPA, S_MU, S_RG, S_GAMMA, S_ETA, S_RHAT_G, S_RHAT_TK, S_DTAU, S_DKAPPA,
+    S_ALPHA_PRED, S_ALPHA, S_CP, S_BQ, S_RP0, S_RD0, S_RG0, S_RMU0, S_COUNT
+};
+enum { ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_UNBOUNDED = 2, ST_UNFINISHED = 3 };  // indicators.rs:85-90
+enum { FLAG_NAN_PQ = 1 };
+
+// read back once per iteration (96 bytes)
+struct StatusRec {
+    double alpha, rho_p, rho_d, rho_A, rho_g, rho_mu, obj, tau, kappa;
+    int32_t status, potrf_info, flags, pad_;
+};
+
+struct VecArgs {
+    int n, m, np, mp, nblk, nsplit;
+    // problem
+    const double *b, *c;
+    // iterate
+    double *x, *y, *z;
+    // work vectors (n-sized: np doubles; m-sized: mp doubles)
+    double *dinv, *xs, *r1, *rD, *p, *u, *dx, *dz, *dxdz;   // n
+    double *rP, *rP2, *q, *dy, *Ax;                          // m
+    double *W;        // [2][np]  gemv_n inputs
+    double *R;        // [2][mp]  gemv_n outputs / solve in-out
+    const double* ATpart;  // [nsplit][nrhs][np] gemv_t slabs
+    double *S, *red;
+    StatusRec* status;
+    int32_t *potrf_info;
+    int *flags;
+};
+
+void vec_blind_start(const VecArgs& a, hipStream_t st);
+void vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st);
+void vec_pred_setup(const VecArgs& a, hipStream_t st);
+void vec_pq_uv(const VecArgs& a, hipStream_t st);
+void vec_uv_corr(const VecArgs& a, hipStream_t st);
+void vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st);
+void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
+void vec_step(const VecArgs& a, int ip, hipStream_t st);
+void vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st);
+
+hipError_t launch_chol_solve_ws(const double* L, int64_t ld, const double* invL, int mp, int nrhs,
+                                double* R, double* Yscratch, hipStream_t st);
+
+}  // namespace lpipm

@@ -1,0 +1,127 @@
+"""Per-kernel parity: every HIP stage of the hot path, called through the C ABI (include/lpipm.h),
+against the oracle's restatement of the reference lines it replaces.  fp64; tolerances are relative
+to the natural scale of each result and written next to each check.  Reference parity at this
+granularity is unpinned (the reference has no fixture for M / factor / solve; oracle_ipm.h)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 4), (16, 16), (100, 130), (128, 256), (200, 333), (257, 700), (512, 1024)]
+
+
+def _rand_problem(m, n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((m, n))
+    d = np.exp(rng.uniform(-6, 6, n))          # x/z spans many orders of magnitude late in a solve
+    return A, d, rng
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_adat_matches_oracle(ctx, m, n):
+    """newton_equations.rs:54-57.  |M_gpu - M_ref| <= 1e-13 * sqrt(n) * max|M| on the lower triangle."""
+    from oracle import capi as oracle
+    A, d, rng = _rand_problem(m, n, 1)
+    ctx.upload_arrays(A, rng.standard_normal(m), rng.standard_normal(n))
+    M, _ = ctx.k_adat(d)
+    Mref = oracle.adat(A, d)
+    il = np.tril_indices(m)
+    err = np.abs(M[il] - Mref[il]).max()
+    assert err <= 1e-13 * np.sqrt(n) * np.abs(Mref).max(), err
+
+
+def test_adat_asymmetric_layout(ctx):
+    """A = [I 0]-like rows with distinct scales: catches a transposed C/D fragment map (row<->col)."""
+    m, n = 128, 256
+    A = np.zeros((m, n))
+    A[np.arange(m), np.arange(m)] = 1.0
+    A[np.arange(1, m), np.arange(m - 1)] += np.arange(1, m) * 0.5     # M[i, i-1] != M[i-1, i] pattern check
+    d = np.arange(1, n + 1, dtype=float)
+    ctx.upload_arrays(A, np.ones(m), np.ones(n))
+    M, _ = ctx.k_adat(d)
+    Mref = (A * d) @ A.T
+    il = np.tril_indices(m)
+    assert np.abs(M[il] - Mref[il]).max() <= 1e-12 * np.abs(Mref).max()
+
+
+@pytest.mark.parametrize("m", [3, 16, 100, 128, 200, 257, 512, 1024])
+def test_potrf_and_solve(ctx, m):
+    """newton_equations.rs:129-131 and :151-169.  L L^T reproduces M to 1e-13 relative; the solve has a
+    relative residual |M v - r| / (|M||v|) <= 1e-13 and agrees with the oracle's substitution to
+    1e-9 relative (cond(M) ~ 1e3..1e5 here)."""
+    from oracle import capi as oracle
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, 2 * m + 3))
+    M = B @ B.T + 1e-3 * np.eye(m)
+    L, info, _ = ctx.k_potrf(M)
+    assert info == 0
+    L = np.tril(L)
+    assert np.abs(L @ L.T - M).max() <= 1e-13 * np.abs(M).max() * np.sqrt(m)
+    rc, Lref = oracle.cholesky(M)
+    assert rc == 0
+    assert np.abs(L - Lref).max() <= 1e-10 * np.abs(Lref).max()
+    for nrhs in (1, 2):
+        R = rng.standard_normal((nrhs, m))
+        V, _ = ctx.k_chol_solve(m, R)
+        for q in range(nrhs):
+            resid = np.abs(M @ V[q] - R[q]).max()
+            assert resid <= 1e-12 * (np.abs(M).sum(axis=1).max() * np.abs(V[q]).max()), resid
+            vref = oracle.cholesky_solve(Lref, R[q])
+            assert np.abs(V[q] - vref).max() <= 1e-9 * np.abs(vref).max()
+
+
+def test_potrf_reports_nonpositive_pivot(ctx):
+    """A failed factorisation must surface (newton_equations.rs:59-63 -> NumericalProblem)."""
+    m = 200
+    rng = np.random.default_rng(7)
+    B = rng.standard_normal((m, m + 5))
+    M = B @ B.T
+    M[150, 150] = -1.0
+    _, info, _ = ctx.k_potrf(M)
+    assert 1 <= info <= 151
+
+
+@pytest.mark.parametrize("m,n", SHAPES)
+def test_gemv_n_t(ctx, m, n):
+    """A.w and A^T.v (feasible_point.rs:122-123, newton_equations.rs:220,223): 1e-13*sqrt(k) relative."""
+    from oracle import capi as oracle
+    A, _, rng = _rand_problem(m, n, 2)
+    ctx.upload_arrays(A, rng.standard_normal(m), rng.standard_normal(n))
+    W = rng.standard_normal((2, n))
+    V = rng.standard_normal((2, m))
+    for nrhs in (1, 2):
+        Y, _ = ctx.k_gemv_n(W[:nrhs])
+        U, _ = ctx.k_gemv_t(V[:nrhs])
+        for q in range(nrhs):
+            yref, uref = oracle.gemv_n(A, W[q]), oracle.gemv_t(A, V[q])
+            assert np.abs(Y[q] - yref).max() <= 1e-13 * np.sqrt(n) * max(1.0, np.abs(yref).max())
+            assert np.abs(U[q] - uref).max() <= 1e-13 * np.sqrt(m) * max(1.0, np.abs(uref).max())
+
+
+def test_adat_linearity_full_size(ctx):
+    """Size-independent property at the headline size (m=4096, n=8192): M(d1 + d2) = M(d1) + M(d2)
+    and M(e_k) = a_k a_k^T, without running the oracle at full size."""
+    m, n = 4096, 8192
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((m, n))
+    ctx.upload_arrays(A, np.zeros(m), np.zeros(n))
+    d1, d2 = rng.uniform(0.1, 2.0, n), rng.uniform(0.1, 2.0, n)
+    M1, _ = ctx.k_adat(d1)
+    M2, _ = ctx.k_adat(d2)
+    M12, _ = ctx.k_adat(d1 + d2)
+    il = np.tril_indices(m)
+    scale = np.abs(M12[il]).max()
+    assert np.abs(M12[il] - (M1[il] + M2[il])).max() <= 1e-12 * scale
+    e = np.zeros(n)
+    e[1234] = 1.0
+    Me, _ = ctx.k_adat(e)
+    ref = np.outer(A[:, 1234], A[:, 1234])
+    assert np.abs(Me[il] - ref[il]).max() <= 1e-14 * np.abs(ref).max()
+    # a spot block against numpy
+    blk = (A[3000:3100] * d1) @ A[100:260].T
+    assert np.abs(M1[3000:3100, 100:260] - blk).max() <= 1e-13 * np.sqrt(n) * np.abs(blk).max()
+
+
+def test_mfma_probe_runs(ctx):
+    tf, ms = ctx.k_mfma_f64_probe(2000)
+    assert tf > 1.0 and ms > 0.0

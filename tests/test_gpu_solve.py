@@ -1,0 +1,155 @@
+"""End-to-end parity of the HIP path (through the reference-shaped API of lp_amd and the C ABI):
+the reference's own known-answer tests, then planted dense LPs against the CPU oracle on the same
+inputs: same status, SAME iteration count, |x_gpu - x_oracle|_inf <= 1e-6 (BASELINE.json: "within
+1e-6 abs in fp64"), per-iteration indicators to 1e-6 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+X_TOL = 1e-6   # north_star tolerance on x (abs, fp64)
+
+
+def _readme_problem(lp):
+    return (lp.Problem.target([-1.0, 4.0]).ub([[-3.0, 1.0], [1.0, 2.0]], [6.0, 4.0])
+            .eq([[1.0, 1.0]], [1.0]).build())
+
+
+def test_crate_doctest_readme_lp(built):
+    """src/lib.rs:17-52, :106-113; interior_point/mod.rs:256-273."""
+    import lp_amd as lp
+    solver = (lp.InteriorPoint.custom().solver_type(lp.EquationSolverType.Cholesky).tol(1e-8).disp(False)
+              .ip(True).alpha0(0.99995).max_iter(1000).build())
+    res = solver.solve(_readme_problem(lp))
+    assert np.abs(res.x() - np.array([1.0, 0.0])).max() < 1e-6
+    assert res.iteration() == 4                      # oracle / SURVEY 8c trajectory
+    assert abs(res.fun() - (-1.0)) < 1e-6
+
+
+def test_custom_doctest_ub_only(built):
+    """interior_point/mod.rs:175-194."""
+    import lp_amd as lp
+    prob = lp.Problem.target([-1.0, 4.0]).ub([[-3.0, 1.0], [1.0, 2.0]], [6.0, 4.0]).build()
+    res = lp.InteriorPoint.custom().build().solve(prob)
+    assert np.abs(res.x() - np.array([4.0, 0.0])).max() < 1e-6
+    assert res.iteration() == 5
+
+
+def test_linprog_eq_only(built):
+    """interior_point/mod.rs:319-331."""
+    import lp_amd as lp
+    A = [[2.0, 1.0, 0.0], [0.0, 2.0, 1.0], [1.0, 0.0, 2.0]]
+    prob = lp.Problem.target([-1.0, 4.0, -1.2]).eq(A, [1.0, 2.0, 3.0]).build()
+    res = lp.InteriorPoint.default().solve(prob)
+    assert np.abs(res.x() - np.array([1 / 3, 1 / 3, 4 / 3])).max() < 1e-6
+    assert res.iteration() == 3
+
+
+def test_linprog_ub_only(built):
+    """interior_point/mod.rs:332-344."""
+    import lp_amd as lp
+    A = [[2.0, 1.0, 0.0], [0.0, 2.0, 1.0], [1.0, 0.0, 2.0]]
+    prob = lp.Problem.target([-1.0, 4.0, -1.2]).ub(A, [1.0, 2.0, 3.0]).build()
+    res = lp.InteriorPoint.default().solve(prob)
+    assert np.abs(res.x() - np.array([0.5, 0.0, 1.25])).max() < 1e-6
+    assert res.iteration() == 6
+
+
+def test_example_symmetric_1000(built):
+    """examples/symmetric.rs:10-25: ub 1000x1000 `1 - I`, b = 999, c = -1 -> all-ones within 1e-10."""
+    import lp_amd as lp
+    N = 1000
+    prob = lp.Problem.target(-np.ones(N)).ub(1.0 - np.eye(N), np.full(N, N - 1.0)).build()
+    res = lp.InteriorPoint.custom().build().solve(prob)
+    assert np.abs(res.x() - 1.0).max() < 1e-10
+    assert res.iteration() == 4
+    assert abs(res.fun() + 1000.0) < 1e-6
+
+
+def test_readme_trajectory_matches_oracle(built):
+    """Per-iteration alpha and indicators of C1 against the oracle, 1e-6 relative."""
+    import lp_amd as lp
+    from oracle import capi as oracle
+    prob = _readme_problem(lp)
+    ctx = lp.default_context(0).upload(prob)
+    res = lp.InteriorPoint.default().solve_uploaded(ctx, prob, want_log=True)
+    ref = oracle.solve(prob.A(), prob.b(), prob.c())
+    assert res.iteration() == ref["iterations"] == 4
+    got, exp = np.array(res.log), np.array(ref["log"])
+    assert np.abs(got - exp).max() <= 1e-6 * np.maximum(1.0, np.abs(exp)).max()
+    assert np.abs(got[:, 1:6] / exp[:, 1:6] - 1.0).max() < 1e-5   # rho_* relative, incl. the 1e-11 ones
+
+
+def test_unsupported_solver_types_fail_loudly(built):
+    """Inverse / LeastSquares (newton_equations.rs:133-149) are SURVEY 8(f) "next" rows: the HIP backend
+    must refuse them, not fall back to anything."""
+    import lp_amd as lp
+    prob = _readme_problem(lp)
+    for st in (lp.EquationSolverType.Inverse, lp.EquationSolverType.LeastSquares):
+        with pytest.raises(lp.BackendError):
+            lp.InteriorPoint.custom().solver_type(st).build().solve(prob)
+
+
+def test_infeasible_unbounded_iteration_limit(built):
+    """Exits the reference never tests but defines: indicators.rs:66-83, mod.rs:232-239."""
+    import lp_amd as lp
+    from oracle import capi as oracle
+    with pytest.raises(lp.Infeasible):
+        lp.InteriorPoint.default().solve(lp.Problem.target([1.0, 1.0]).eq([[1.0, 1.0]], [-1.0]).build())
+    with pytest.raises(lp.Unbounded):
+        lp.InteriorPoint.default().solve(lp.Problem.target([-1.0, 0.0]).eq([[1.0, -1.0]], [0.0]).build())
+    prob = _readme_problem(lp)
+    with pytest.raises(lp.IterationLimitExceeded) as ei:
+        lp.InteriorPoint.custom().max_iter(2).build().solve(prob)
+    ref = oracle.solve(prob.A(), prob.b(), prob.c(), 0.0, oracle.default_opts(max_iter=2))
+    assert ref["status"] == oracle.ITERATION_LIMIT
+    assert np.abs(ei.value.x - ref["x_slack"]).max() < 1e-9      # payload = x / tau (error.rs:26-28)
+
+
+@pytest.mark.parametrize("m,n,seed", [(64, 128, 0), (100, 333, 1), (256, 512, 0), (256, 512, 1),
+                                      (512, 1024, 0), (1024, 2048, 0)])
+def test_planted_lp_matches_oracle(ctx, m, n, seed):
+    """BASELINE configs C2 / C4 shapes (+ ragged): GPU vs the CPU oracle on the same seeded input."""
+    import lp_amd as lp
+    from lp_amd import synth
+    from oracle import capi as oracle
+    A, b, c, xstar = synth.planted_lp(seed, m, n)
+    ctx.upload_arrays(A, b, c)
+    rc, x, fun, it, rows = ctx.solve_raw(lp.InteriorPoint.default().opts(), want_log=True)
+    ref = oracle.solve(A, b, c)
+    assert rc == 0 and ref["status"] == 0
+    assert it == ref["iterations"], (it, ref["iterations"])
+    assert np.abs(x - ref["x_slack"]).max() <= X_TOL
+    assert abs(fun - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
+    assert np.abs(x - xstar).max() < 1e-4        # both sit on the planted vertex
+    got, exp = np.array(rows), np.array(ref["log"])
+    assert np.abs(got[:, 0] - exp[:, 0]).max() < 1e-6            # step lengths
+
+
+def test_ub_form_slack_structure(ctx):
+    """linear_program.rs:145-156: A = [A_ub I] through the full path vs the oracle."""
+    import lp_amd as lp
+    from oracle import capi as oracle
+    rng = np.random.default_rng(5)
+    m, n = 150, 220
+    A_ub = rng.standard_normal((m, n))
+    x0 = rng.uniform(0.5, 1.5, n)
+    b_ub = A_ub @ x0 + rng.uniform(0.1, 1.0, m)
+    c = A_ub.T @ (-rng.uniform(0.1, 1.0, m)) + rng.uniform(0.1, 1.0, n)  # bounded: c = -A^T w + s, w,s > 0
+    prob = lp.Problem.target(c).ub(A_ub, b_ub).build()
+    res = lp.InteriorPoint.default().solve(prob)
+    ref = oracle.solve(prob.A(), prob.b(), prob.c())
+    assert ref["status"] == 0 and res.iteration() == ref["iterations"]
+    assert np.abs(res.x() - ref["x_slack"][:n]).max() <= X_TOL
+
+
+def test_repeat_solve_is_bitwise_deterministic(ctx):
+    """Fixed-order reductions everywhere: two solves of the same upload agree bit for bit."""
+    import lp_amd as lp
+    from lp_amd import synth
+    A, b, c, _ = synth.planted_lp(3, 256, 512)
+    ctx.upload_arrays(A, b, c)
+    o = lp.InteriorPoint.default().opts()
+    r1 = ctx.solve_raw(o)
+    r2 = ctx.solve_raw(o)
+    assert r1[3] == r2[3] and np.array_equal(r1[1], r2[1])
