@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- IPM iterations/sec on the headline workload of BASELINE.json (dense 4096x8192 fp64 LP).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one complete `InteriorPoint::solve` (mod.rs:199-240) of the rank's LP: the whole hot path
+(A.D.A^T, Cholesky, triangular solves, GEMVs, vector kernels) for as many IPM iterations as the
+solver needs, with A already resident in HBM (uploaded once before the timed region).
+Weak scaling: every rank owns ONE independent LP of the same shape (seed = rank) -- the batch shards
+one per GPU with no data-path collective -- and the timed region ends with the single RCCL
+all-gather of the solutions.  value = IPM iterations of all ranks / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline     : the dominant kernel (A.D.A^T, MFMA-bound): algorithmic flops m(m+1)n per launch /
+                 its average launch duration from HIP events recorded on the solver's own stream
+                 INSIDE the timed region; peak = 78.6 TFLOP/s dense fp64 MFMA.
+  cpu_baseline : rank 0, N == 1 only: the single-threaded C restatement of the reference
+                 (oracle/, kind "port") timed on this box's host for ONE IPM iteration of the same LP
+                 (every iteration performs the same operations, so 1 / t is its iterations/sec).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (probe: lpipm_k_mfma_f64_probe ~76 TF/s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import lp_amd
+    from lp_amd import synth
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    m, n = args.m, args.n
+    A, b, c, xstar = synth.planted_lp(rank, m, n)        # one independent LP per rank (seed = rank)
+    ctx = lp_amd.Context(local_rank)
+    ctx.upload_arrays(A, b, c)                           # one-time H2D, outside the timed region
+    solver = lp_amd.InteriorPoint.default()              # reference defaults (mod.rs:52-59)
+    opts = solver.opts()
+    x_dev = torch.zeros(n, dtype=torch.float64, device=dev)
+    gathered = torch.zeros(world * n, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        rc, _, fun, its, _ = ctx.solve_raw(opts, x_dev_ptr=x_dev.data_ptr())
+        if rc != 0:
+            raise RuntimeError(f"solve failed with status {rc}")
+        if dist is not None:                             # the single RCCL gather of the batch's solutions
+            dist.all_gather_into_tensor(gathered, x_dev)
+        return its, fun
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.set_profiling(True)                              # HIP events around each phase, solver's own stream
+    adat_ms = 0.0
+    adat_launches = 0
+    phase = {k: 0.0 for k in ("adat_ms", "potrf_ms", "trsv_ms", "gemv_ms", "vec_ms", "total_ms")}
+    iters_local = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        its, fun = one_step()
+        iters_local += its
+        pt = ctx.phase_times()
+        adat_ms += pt["adat_ms"]
+        adat_launches += pt["adat_launches"]
+        for k in phase:
+            phase[k] += pt[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.set_profiling(False)
+
+    # parity guard on what was just timed: the planted vertex is the known answer
+    err = float((x_dev.cpu().numpy() - xstar).__abs__().max())
+
+    if dist is not None:
+        t = torch.tensor([dt, float(iters_local)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, iters_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, iters_total = dt, float(iters_local)
+
+    if rank == 0:
+        flops_per_launch = float(m) * (m + 1) * n                     # lower triangle of A.D.A^T
+        avg_ms = adat_ms / max(adat_launches, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "IPM iterations/sec, dense 4096x8192 fp64 LP",
+            "value": iters_total / dt_max,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C3: random dense planted LP m={m} n={n} fp64, one independent LP per GPU "
+                                   f"(seed = rank), reference default options, A resident in HBM",
+                       "m": m, "n": n, "iterations_per_solve": iters_local / args.steps,
+                       "max_abs_err_vs_planted_optimum": err},
+            "roofline": {"kernel": "gemm_nt_kernel (A.diag(x/z).A^T, lower tiles, fp64 MFMA 16x16x4)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": avg_ms, "launches": adat_launches,
+                         "flops_per_launch": flops_per_launch},
+            "phase_ms_per_iteration": {k: v / max(iters_local, 1) for k, v in phase.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import capi as oracle                        # checker / baseline only
+            o = oracle.default_opts(max_iter=1)
+            t1 = time.perf_counter()
+            r = oracle.solve(A, b, c, 0.0, o, want_log=False)
+            tc = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": 1.0 / r["timing"]["total"], "unit": "iterations/s", "cores": 1, "kind": "port",
+                "sample": f"1 IPM iteration (the first) of the same {m}x{n} LP with the single-threaded C "
+                          f"restatement of the reference (as-written op counts); {tc:.1f} s of CPU work; "
+                          f"every iteration performs the same operations",
+                "phase_s": r["timing"],
+            }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

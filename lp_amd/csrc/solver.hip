@@ -41,6 +41,7 @@ struct lpipm_ctx {
     int mp = 0, np = 0, nblk = 1, nsplit = 1;
     double c0 = 0.0;
     std::vector<void*> allocs;   // problem-sized device buffers
+    std::vector<size_t> alloc_bytes;
     std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
     // problem + state + work
     double *A = nullptr, *M = nullptr, *invL = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
@@ -69,11 +70,12 @@ static int free_list(std::vector<void*>& v) {
     return 0;
 }
 template <typename T>
-static int dalloc(std::vector<void*>& list, T** out, size_t count, hipStream_t st) {
+static int dalloc(std::vector<void*>& list, std::vector<size_t>* sizes, T** out, size_t count, hipStream_t st) {
     void* p = nullptr;
     const size_t bytes = (count ? count : 1) * sizeof(T);
     LP_HIP(hipMalloc(&p, bytes));
     list.push_back(p);
+    if (sizes) sizes->push_back(bytes);
     LP_HIP(hipMemsetAsync(p, 0, bytes, st));
     *out = (T*)p;
     return LPIPM_OK;
@@ -221,6 +223,7 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
     if (!c->has_problem || mp != c->mp || np != c->np) {
         LP_HIP(hipStreamSynchronize(c->st));
         free_list(c->allocs);
+        c->alloc_bytes.clear();
         c->has_problem = false;
         c->mp = mp; c->np = np;
         c->nsplit = mp / GEMVT_ROWS;
@@ -230,39 +233,41 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
         VecArgs& v = c->va;
         auto& L = c->allocs;
         hipStream_t st = c->st;
-        LP_TRY(dalloc(L, &c->A, (size_t)mp * np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->A, (size_t)mp * np, st));
         double *bb, *ccv;
-        LP_TRY(dalloc(L, &bb, (size_t)mp, st)); LP_TRY(dalloc(L, &ccv, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &bb, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &ccv, (size_t)np, st));
         v.b = bb; v.c = ccv;
-        LP_TRY(dalloc(L, &v.x, (size_t)np, st)); LP_TRY(dalloc(L, &v.y, (size_t)mp, st)); LP_TRY(dalloc(L, &v.z, (size_t)np, st));
-        LP_TRY(dalloc(L, &v.dinv, (size_t)np, st)); LP_TRY(dalloc(L, &v.xs, (size_t)np, st)); LP_TRY(dalloc(L, &v.r1, (size_t)np, st));
-        LP_TRY(dalloc(L, &v.rD, (size_t)np, st)); LP_TRY(dalloc(L, &v.p, (size_t)np, st)); LP_TRY(dalloc(L, &v.u, (size_t)np, st));
-        LP_TRY(dalloc(L, &v.dx, (size_t)np, st)); LP_TRY(dalloc(L, &v.dz, (size_t)np, st)); LP_TRY(dalloc(L, &v.dxdz, (size_t)np, st));
-        LP_TRY(dalloc(L, &v.rP, (size_t)mp, st)); LP_TRY(dalloc(L, &v.rP2, (size_t)mp, st)); LP_TRY(dalloc(L, &v.q, (size_t)mp, st));
-        LP_TRY(dalloc(L, &v.dy, (size_t)mp, st)); LP_TRY(dalloc(L, &v.Ax, (size_t)mp, st));
-        LP_TRY(dalloc(L, &v.W, (size_t)2 * np, st)); LP_TRY(dalloc(L, &v.R, (size_t)2 * mp, st));
-        LP_TRY(dalloc(L, &c->Y, (size_t)2 * mp, st));
-        LP_TRY(dalloc(L, &c->ATpart, (size_t)c->nsplit * 2 * np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.x, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.y, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.z, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dinv, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.xs, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.r1, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.rD, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.p, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.u, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dx, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.dz, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.dxdz, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.rP, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.rP2, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.q, (size_t)mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dy, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.Ax, (size_t)mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.W, (size_t)2 * np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.R, (size_t)2 * mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->Y, (size_t)2 * mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->ATpart, (size_t)c->nsplit * 2 * np, st));
         v.ATpart = c->ATpart;
-        LP_TRY(dalloc(L, &v.S, (size_t)64, st)); LP_TRY(dalloc(L, &v.red, (size_t)RED_SLOTS * RED_STRIDE, st));
-        LP_TRY(dalloc(L, &v.status, 1, st));
-        LP_TRY(dalloc(L, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &v.flags, 1, st));
-        LP_TRY(dalloc(L, &c->M, (size_t)mp * mp, st));
-        LP_TRY(dalloc(L, &c->invL, (size_t)(mp / NB) * NB * NB, st));
-        LP_TRY(dalloc(L, &c->xout, (size_t)np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.S, (size_t)64, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.red, (size_t)RED_SLOTS * RED_STRIDE, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.status, 1, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.flags, 1, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->M, (size_t)mp * mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->invL, (size_t)(mp / NB) * NB * NB, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->xout, (size_t)np, st));
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
         c->ntiles = (int)order.size();
         c->adat_nwg = gemm_streamk_nwg(c->ntiles, np / BK, c->num_cu);
-        LP_TRY(dalloc(L, &c->tile_list, order.size(), st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->tile_list, order.size(), st));
         LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        LP_TRY(dalloc(L, &c->ws, (size_t)2 * c->adat_nwg * TILE * TILE, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->ws, (size_t)2 * c->adat_nwg * TILE * TILE, st));
         LP_HIP(hipStreamSynchronize(st));  // `order` must outlive the copy
         v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
     } else {
-        LP_HIP(hipMemsetAsync(c->A, 0, (size_t)mp * np * sizeof(double), c->st));
-        LP_HIP(hipMemsetAsync((void*)c->va.b, 0, (size_t)mp * sizeof(double), c->st));
-        LP_HIP(hipMemsetAsync((void*)c->va.c, 0, (size_t)np * sizeof(double), c->st));
+        // same padded geometry: clear everything but the constant tile list, so no stale (possibly
+        // non-finite) value of a previous problem can sit in a padding lane
+        for (size_t i = 0; i < c->allocs.size(); ++i)
+            if (c->allocs[i] != (void*)c->tile_list)
+                LP_HIP(hipMemsetAsync(c->allocs[i], 0, c->alloc_bytes[i], c->st));
     }
     c->m = m; c->n = n; c->c0 = c0;
     c->va.n = (int)n; c->va.m = (int)m;
@@ -496,12 +501,12 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_HIP(hipStreamSynchronize(c->st));
     free_list(c->kallocs);
     c->kmp = 0;
-    LP_TRY(dalloc(c->kallocs, &c->kM, (size_t)mp * mp, c->st));
-    LP_TRY(dalloc(c->kallocs, &c->kM0, (size_t)mp * mp, c->st));
-    LP_TRY(dalloc(c->kallocs, &c->kinvL, (size_t)(mp / NB) * NB * NB, c->st));
-    LP_TRY(dalloc(c->kallocs, &c->kR, (size_t)2 * mp, c->st));
-    LP_TRY(dalloc(c->kallocs, &c->kY, (size_t)2 * mp, c->st));
-    LP_TRY(dalloc(c->kallocs, &c->kinfo, 1, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kM, (size_t)mp * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kM0, (size_t)mp * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kinvL, (size_t)(mp / NB) * NB * NB, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kR, (size_t)2 * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kY, (size_t)2 * mp, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
     c->kmp = mp;
     return LPIPM_OK;
 }
