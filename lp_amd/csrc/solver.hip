@@ -13,6 +13,7 @@
 //     indicators just took (residual.rs:22-26) at the same point;
 //   * the predictor's two sym_solve calls share one pass over A per GEMV and one 2-RHS solve.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -30,6 +31,7 @@ void set_error_detail(const char* what, hipError_t e, const char* file, int line
 }
 }  // namespace lpipm
 
+namespace lpipm { extern long long* g_diag_stamps; }
 enum { T_VEC = 0, T_ADAT, T_POTRF, T_TRSV, T_GEMV, T_NTAGS };
 
 struct lpipm_ctx {
@@ -539,6 +541,22 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
         total += ms;
     }
     if (ms_out) *ms_out = total / repeats;
+    if (getenv("LPIPM_DIAG_STAMPS")) {  // debug aid: cycle stamps of the first diagonal-block kernel
+        long long* d = nullptr; long long h[16] = {0};
+        if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
+            g_diag_stamps = d;
+            (void)hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st);
+            (void)launch_potrf(c->kM, mp, mp, c->kinvL, c->kinfo, c->st);
+            (void)hipStreamSynchronize(c->st);
+            g_diag_stamps = nullptr;
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            fprintf(stderr, "diag stamps (cycles): elim16(jb=0) %lld, update(jb=0) %lld, all 8 blocks %lld, writeL %lld, inverse %lld, writeInv %lld\n",
+                    h[1]-h[0], h[2]-h[1], h[3]-h[0], h[5]-h[4], h[6]-h[5], h[7]-h[6]);
+            fprintf(stderr, "  elim detail: load a %lld, 16 steps %lld, rsqrt scale %lld, write back %lld, barrier %lld\n",
+                    h[8]-h[0], h[9]-h[8], h[10]-h[9], h[11]-h[10], h[1]-h[11]);
+        }
+    }
     int32_t info = 0;
     LP_HIP(hipMemcpyAsync(&info, c->kinfo, sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipMemcpy2DAsync(M_inout, m * sizeof(double), c->kM, (size_t)mp * sizeof(double), m * sizeof(double), m,
