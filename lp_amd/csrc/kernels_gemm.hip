@@ -74,109 +74,124 @@ __device__ __forceinline__ int wg_owner(long long it, long long total, int nwg) 
     return (int)(((it + 1) * (long long)nwg - 1) / total);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmK p) {
-    __shared__ __attribute__((aligned(16))) double lds[2][2][TILE][LDS_STRIDE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
+// acc(128x128 tile, 64 doubles per lane) += sum over k-tiles [kb, ke) of P-panel . (s o Q-panel)^T
+// Pp / Qp point at this thread's first staging element (row srow, column scol of the panels).
+// MTM x MTN = 16x16 MFMA tiles per wave (2x2 waves per workgroup): workgroup tile = 32*MTM x 32*MTN.
+//   4x4 -> 128x128 (throughput launches), 2x2 -> 64x64 and 1x4 -> 32x128 (latency-bound launches)
+template <bool SCALE, int MTM, int MTN>
+__device__ __forceinline__ void tile_mainloop(double (*ldsA)[32 * MTM][LDS_STRIDE], double (*ldsB)[32 * MTN][LDS_STRIDE],
+                                              const double* __restrict__ Pp, long long ldp,
+                                              const double* __restrict__ Qp, long long ldq,
+                                              const double* __restrict__ s, int kb, int ke, d4 (&acc)[MTM][MTN],
+                                              int srow, int scol, int wr, int wc, int fr, int fq) {
+    d2 sa[MTM], sb[MTN];
+    auto gload = [&](int kt) {
+        const long long ko = (long long)kt * BK;
+#pragma unroll
+        for (int r = 0; r < MTM; ++r) sa[r] = *(const d2*)(Pp + (long long)(32 * r) * ldp + ko);
+#pragma unroll
+        for (int r = 0; r < MTN; ++r) sb[r] = *(const d2*)(Qp + (long long)(32 * r) * ldq + ko);
+        if (SCALE) {
+            const d2 sv = *(const d2*)(s + ko + scol);
+#pragma unroll
+            for (int r = 0; r < MTN; ++r) sb[r] = sb[r] * sv;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < MTM; ++r) *(d2*)&ldsA[buf][srow + 32 * r][scol] = sa[r];
+#pragma unroll
+        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = sb[r];
+    };
+    gload(kb);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kb; kt < ke; ++kt) {
+        const bool more = kt + 1 < ke;
+        if (more) gload(kt + 1);
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            d2 a[MTM], b[MTN];
+#pragma unroll
+            for (int mi = 0; mi < MTM; ++mi)
+                a[mi] = *(const d2*)&ldsA[cur][wr * (16 * MTM) + mi * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int nj = 0; nj < MTN; ++nj)
+                b[nj] = *(const d2*)&ldsB[cur][wc * (16 * MTN) + nj * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < MTN; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// C tile <- beta*C + alpha*acc.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15,
+// row = (lane>>4) + 4*reg.  Per-lane base pointer + wave-uniform row offsets keep the address math
+// in SGPRs.  cb = &C[tile_row0 + wr*16*MTM + fq][tile_col0 + wc*16*MTN + fr].
+template <int MTM, int MTN>
+__device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (&acc)[MTM][MTN], double alpha,
+                                           double beta, bool pad_diag, int row0, int diag_pad_from, int fr, int fq) {
+#pragma unroll
+    for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* rp = cb + (long long)(mi * 16 + 4 * r) * ldc;
+#pragma unroll
+            for (int nj = 0; nj < MTN; ++nj) {
+                double v = alpha * acc[mi][nj][r];
+                if (beta != 0.0) v += beta * rp[nj * 16];
+                if (pad_diag && mi == nj && fq + 4 * r == fr && row0 + mi * 16 + 4 * r >= diag_pad_from) v = 1.0;
+                rp[nj * 16] = v;
+            }
+        }
+}
+
+#define TILE_THREAD_IDS                                                    \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;         \
+    const int wr = wave >> 1, wc = wave & 1;                               \
+    const int fr = lane & 15, fq = lane >> 4;                              \
+    const int srow = tid >> 3;  /* staging: 32 rows per pass, 8 lanes per 128-B row segment */ \
+    const int scol = (tid & 7) * 2;
+
+// Stream-K A.D.A^T (also usable unscaled): ntiles*KT k-tile iterations split evenly over the grid.
+template <bool SCALE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) {
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
+    TILE_THREAD_IDS
     const int g = xcd_remap(blockIdx.x, gridDim.x);
-
     const int KT = p.KT;
     const long long total = (long long)p.ntiles * KT;
     long long it = wg_begin(g, total, p.nwg);
     const long long end = wg_begin(g + 1, total, p.nwg);
     bool first = true;
-
-    const int srow = tid >> 3;        // staging: 32 rows per pass, 8 lanes per 128-B row segment
-    const int scol = (tid & 7) * 2;
-
     while (it < end) {
         const int tile = (int)(it / KT);
         const int kb = (int)(it - (long long)tile * KT);
         const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
         int ti, tj;
         tile_coords(p, tile, ti, tj);
-        const double* Pp = p.P + (long long)(ti * TILE + srow) * p.ldp + scol;
-        const double* Qp = p.Q + (long long)(tj * TILE + srow) * p.ldq + scol;
-
         d4 acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
-
-        d2 sa[4], sb[4];
-        auto gload = [&](int kt) {
-            const long long ko = (long long)kt * BK;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sa[r] = *(const d2*)(Pp + (long long)(32 * r) * p.ldp + ko);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sb[r] = *(const d2*)(Qp + (long long)(32 * r) * p.ldq + ko);
-            if (p.s) {
-                const d2 sv = *(const d2*)(p.s + ko + scol);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sb[r] = sb[r] * sv;
-            }
-        };
-        auto lstore = [&](int buf) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *(d2*)&lds[buf][0][srow + 32 * r][scol] = sa[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) *(d2*)&lds[buf][1][srow + 32 * r][scol] = sb[r];
-        };
-
-        gload(kb);
-        lstore(0);
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kb; kt < ke; ++kt) {
-            const bool more = kt + 1 < ke;
-            if (more) gload(kt + 1);
-#pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                d2 a[4], b[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    a[mi] = *(const d2*)&lds[cur][0][wr * 64 + mi * 16 + fr][round * 8 + fq * 2];
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj)
-                    b[nj] = *(const d2*)&lds[cur][1][wc * 64 + nj * 16 + fr][round * 8 + fq * 2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int nj = 0; nj < 4; ++nj)
-                            acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t],
-                                                                                acc[mi][nj], 0, 0, 0);
-            }
-            if (more) lstore(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
-
-        // ---- epilogue.  C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg.
-        // Per-lane base pointer + wave-uniform row offsets keep the address math in SGPRs.
-        const bool full = (kb == 0 && ke == KT);
-        if (full) {
+        tile_mainloop<SCALE, 4, 4>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
+                             p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow,
+                             scol, wr, wc, fr, fq);
+        if (kb == 0 && ke == KT) {
             double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 64 + fr);
-            const bool pad_diag = p.diag_pad_from >= 0 && ti == tj && wr == wc;
-            const int row0 = ti * TILE + wr * 64 + fq;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double* rp = cb + (long long)(mi * 16 + 4 * r) * p.ldc;
-#pragma unroll
-                    for (int nj = 0; nj < 4; ++nj) {
-                        double v = p.alpha * acc[mi][nj][r];
-                        if (p.beta != 0.0) v += p.beta * rp[nj * 16];
-                        if (pad_diag && mi == nj && fq + 4 * r == fr && row0 + mi * 16 + 4 * r >= p.diag_pad_from)
-                            v = 1.0;
-                        rp[nj * 16] = v;
-                    }
-                }
+            tile_store<4, 4>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj && wr == wc,
+                       ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
         } else {
             double* sb0 = p.ws + ((long long)(2 * g + (first ? 0 : 1))) * (TILE * TILE) +
                           (wr * 64 + fq) * TILE + wc * 64 + fr;
@@ -185,12 +200,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmK p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int nj = 0; nj < 4; ++nj)
-                        sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
+                    for (int nj = 0; nj < 4; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
         }
         it += ke - kb;
         first = false;
     }
+}
+
+// One full tile per workgroup (Cholesky trailing update, TRSM-as-GEMM): no k-split, no slabs.
+// Tile coordinates are in units of (32*MTM rows, 32*MTN columns).
+template <int MTM, int MTN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(const GemmK p) {
+    constexpr int TM = 32 * MTM, TN = 32 * MTN;
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TM][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TN][LDS_STRIDE];
+    TILE_THREAD_IDS
+    int ti, tj;
+    tile_coords(p, blockIdx.x, ti, tj);
+    d4 acc[MTM][MTN];
+#pragma unroll
+    for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < MTN; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_mainloop<false, MTM, MTN>(ldsA, ldsB, p.P + (long long)(ti * TM + srow) * p.ldp + scol, p.ldp,
+                                   p.Q + (long long)(tj * TN + srow) * p.ldq + scol, p.ldq, nullptr, 0, p.KT, acc,
+                                   srow, scol, wr, wc, fr, fq);
+    double* cb = p.C + (long long)(ti * TM + wr * (16 * MTM) + fq) * p.ldc + (tj * TN + wc * (16 * MTN) + fr);
+    tile_store<MTM, MTN>(cb, p.ldc, acc, p.alpha, p.beta, false, 0, -1, fr, fq);
+}
+
+// Grouped GEMM: every workgroup takes its own descriptor (operands, k-range, alpha): the doubling
+// levels of the super-block triangular inverse are a few such launches over many small products.
+__global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileDesc* __restrict__ descs) {
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
+    TILE_THREAD_IDS
+    const GemmTileDesc d = descs[blockIdx.x];
+    d4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_mainloop<false, 4, 4>(ldsA, ldsB, d.P + (long long)srow * d.ldp + scol, d.ldp, d.Q + (long long)srow * d.ldq + scol,
+                         d.ldq, nullptr, d.kt_begin, d.kt_end, acc, srow, scol, wr, wc, fr, fq);
+    double* cb = d.C + (long long)(wr * 64 + fq) * d.ldc + (wc * 64 + fr);
+    tile_store<4, 4>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
 }
 
 // Adds the partial slabs of every tile whose k-range was split, in workgroup order.
@@ -237,20 +291,31 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(a.nwg), dim3(256), 0, st, k);
+    if (a.nwg == a.ntiles && !a.s && a.diag_pad_from < 0) {   // one whole tile per workgroup
+        if (a.tile_edge == 64)      hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
+        else if (a.tile_edge == 32) hipLaunchKernelGGL((gemm_nt_tile_kernel<1, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
+        else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
+        return hipGetLastError();
+    }
+    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, dim3(a.nwg), dim3(256), 0, st, k);
+    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, dim3(a.nwg), dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // a split exists unless every workgroup boundary falls on a tile boundary
     const long long total = (long long)a.ntiles * k.KT;
     bool split = false;
-    if (a.nwg != a.ntiles) {
-        for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
-    }
+    for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
     if (split) {
         hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(a.ntiles), dim3(256), 0, st, k);
         e = hipGetLastError();
     }
     return e;
+}
+
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles), dim3(256), 0, st, descs_dev);
+    return hipGetLastError();
 }
 
 }  // namespace lpipm

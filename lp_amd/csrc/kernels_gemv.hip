@@ -22,9 +22,9 @@ constexpr int GN_ROWS_PER_WG   = 4 * GN_ROWS_PER_WAVE;
 template <int NRHS>
 __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, long long lda, int m,
                                                      int np, const double* __restrict__ W, long long ldw,
-                                                     const double* __restrict__ add0,
-                                                     const double* __restrict__ add1,
-                                                     double* __restrict__ Y, long long ldy) {
+                                                     const double* add0,
+                                                     const double* add1,
+                                                     double* Y, long long ldy, double alpha) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * GN_ROWS_PER_WG + wave * GN_ROWS_PER_WAVE;
     if (row0 >= m) return;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
             for (int q = 0; q < NRHS; ++q) {
                 const double* add = q == 0 ? add0 : add1;
                 const double base = add ? add[row0 + r] : 0.0;
-                Y[(long long)q * ldy + row0 + r] = base + acc[r][q];
+                Y[(long long)q * ldy + row0 + r] = base + alpha * acc[r][q];
             }
         }
     }
@@ -110,14 +110,14 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __rest
 
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
-                         hipStream_t st) {
+                         hipStream_t st, double alpha) {
     const int grid = (m + GN_ROWS_PER_WG - 1) / GN_ROWS_PER_WG;
     if (nrhs == 1)
         hipLaunchKernelGGL(gemv_n_kernel<1>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy);
+                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha);
     else
         hipLaunchKernelGGL(gemv_n_kernel<2>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy);
+                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha);
     return hipGetLastError();
 }
 

@@ -139,7 +139,8 @@ __device__ __forceinline__ void trtri_level(double (*Ls)[LS], int wave, int fr, 
     __syncthreads();
 }
 
-// Mblk: top-left of the 128x128 diagonal block (row-major, ld).  Linv: 128x128 row-major slab.
+// Mblk: top-left of the 128x128 diagonal block (row-major, ld).  Linv / LinvT: where inv(L_kk) and
+// its transpose go (row-major, ldinv): the diagonal 128-blocks of the super-block inverses.
 //
 // Factorisation: 8 block columns of 16.  For each, every wave eliminates the 16 columns on
 // 64 rows held one per lane: lanes 0-15 replicate the 16 diagonal rows (so no wave waits on
@@ -151,8 +152,9 @@ __device__ __forceinline__ void trtri_level(double (*Ls)[LS], int wave, int fr, 
 // Inverse: the eight 16x16 diagonal factors are inverted in parallel (one wave each), then three
 // doubling levels (16->32->64->128) of Inv21 = -Inv22.L21.Inv11 on MFMA tiles.
 __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mblk, long long ld,
-                                                        double* __restrict__ Linv, int32_t* info,
-                                                        int global_row0, long long* stamps) {
+                                                        double* __restrict__ Linv, double* __restrict__ LinvT,
+                                                        long long ldinv, int32_t* info, int global_row0,
+                                                        long long* stamps) {
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = clock64(); } while (0)
     __shared__ __attribute__((aligned(16))) double Ls[NB][LS];            // 133,120 B
     __shared__ __attribute__((aligned(16))) double scr[DT / 64][2][SB];   // per-wave column scratch
@@ -302,41 +304,58 @@ __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mbl
         d2 v = *(const d2*)&Ls[r][c];
         if (c > r) v[0] = 0.0;
         if (c + 1 > r) v[1] = 0.0;
-        *(d2*)(Linv + e) = v;
+        *(d2*)(Linv + (long long)r * ldinv + c) = v;
+        // transposed copy (upper triangular), same (r, c) walk so the global stores stay coalesced
+        d2 w = (d2){Ls[c][r], Ls[c + 1][r]};
+        if (r > c) w[0] = 0.0;
+        if (r > c + 1) w[1] = 0.0;
+        *(d2*)(LinvT + (long long)r * ldinv + c) = w;
     }
     STAMP(7);
 #undef STAMP
 }
 
 long long* g_diag_stamps = nullptr;  // debug: device buffer of 8 cycle stamps for block 0 (scripts/)
-hipError_t launch_potrf(double* M, int64_t ld, int mp, double* invL, int32_t* info, hipStream_t st) {
+hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t), st);
     if (e != hipSuccess) return e;
     const int nb = mp / NB;
     for (int k = 0; k < nb; ++k) {
         const int64_t o = (int64_t)k * NB;
         double* diag = M + o * ld + o;
-        double* linv = invL + (int64_t)k * NB * NB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DT), 0, st, diag, (long long)ld, linv, info,
-                           (int)o, (long long*)(k == 0 ? g_diag_stamps : nullptr));
+        double* linv = plan.blk_inv(k);
+        const int ldinv = plan.blk_ld(k);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DT), 0, st, diag, (long long)ld, linv, plan.blk_invT(k),
+                           (long long)ldinv, info, (int)o, (long long*)(k == 0 ? g_diag_stamps : nullptr));
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         const int rem = nb - k - 1;
         if (rem <= 0) break;
         double* panel = M + (o + NB) * ld + o;
         GemmArgs t{};
-        t.P = panel; t.ldp = ld; t.Q = linv; t.ldq = NB; t.s = nullptr;
+        t.P = panel; t.ldp = ld; t.Q = linv; t.ldq = ldinv; t.s = nullptr;
         t.C = panel; t.ldc = ld; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
-        t.ntiles = rem; t.tiles_lower = 0; t.ntj = 1; t.tile_list = nullptr;
-        t.diag_pad_from = -1; t.ws = nullptr; t.nwg = rem;
+        // few tiles -> latency-bound: 32-row x 128-col tiles put 4x as many CUs on the panel, and a
+        // workgroup still owns whole rows, so the product may overwrite its own input
+        t.tile_edge = 32;
+        t.ntiles = 4 * rem; t.tiles_lower = 0; t.ntj = 1; t.tile_list = nullptr;
+        t.diag_pad_from = -1; t.ws = nullptr; t.nwg = t.ntiles;
         e = launch_gemm_nt(t, st);
         if (e != hipSuccess) return e;
         GemmArgs u{};
         u.P = panel; u.ldp = ld; u.Q = panel; u.ldq = ld; u.s = nullptr;
         u.C = M + (o + NB) * ld + (o + NB); u.ldc = ld; u.K = NB; u.alpha = -1.0; u.beta = 1.0;
-        u.ntiles = rem * (rem + 1) / 2; u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
+        u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
+        if (rem * (rem + 1) / 2 < 256) { u.tile_edge = 64; u.ntiles = (2 * rem) * (2 * rem + 1) / 2; }
+        else                           { u.tile_edge = 128; u.ntiles = rem * (rem + 1) / 2; }
         u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles;
         e = launch_gemm_nt(u, st);
+        if (e != hipSuccess) return e;
+    }
+    // inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
+    // grouped launch of stage A (T^T = Inv11^T.L21^T) then stage B (Inv21 = -Inv22.T and its transpose)
+    for (const auto& stg : plan.stages) {
+        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -1,144 +1,219 @@
 // kernels_trsv.hip -- v = L^-T (L^-1 r) with the blocked factor of kernels_potrf.hip
 // (replaces `factor.solvec_into(b2)`, newton_equations.rs:151-169; called from sym_solve :221).
 //
-// Block right-looking substitution with NB = 128 and the explicit inverses of the diagonal blocks
-// (a triangular solve inside a block becomes a dense 128x128 mat-vec, no sequential inner loop):
-//   forward  (k = 0..nb-1):  y_k = inv(L_kk) . r_k ;   r_i -= L_ik . y_k      for i > k
-//   backward (k = nb-1..0):  v_k = inv(L_kk)^T . y_k ; y_j -= L_kj^T . v_k    for j < k
-// One launch per block step (the step's solve is recomputed by every workgroup of the launch, so
-// a step is ONE kernel and needs no inter-workgroup hand-off); 1 or 2 right-hand sides per sweep
-// (the predictor's two sym_solve calls, newton_equations.rs:187-188, share one sweep).
-// HBM-bound: a sweep reads the lower triangle of L once (4 m^2 bytes) + the diagonal inverses.
+// A substitution sweep over mp/128 blocks is mp/128 dependent steps, each a tiny launch: latency,
+// not bytes.  Instead the factor is consumed through the explicit inverses of its diagonal
+// SUPER-blocks (SUPER = 1024 wide; built once per factorisation from the 128-block inverses by
+// log2(8) = 3 doubling levels of Inv21 = -Inv22.L21.Inv11 on the MFMA grouped GEMM):
+//   forward  (k = 0..nsb-1):  y_k = Inv_k . r_k ;      r_below -= L[below, k] . y_k
+//   backward (k = nsb-1..0):  y_k -= L[below, k]^T . v_below ;  v_k = Inv_k^T . y_k
+// Every step is a row-split mat-vec over >= 128 workgroups (no serial inner dependency), so a solve
+// is ~4*nsb launches that stream the lower triangle of L plus the inverses once each (HBM-bound).
+// 1 or 2 right-hand sides per sweep (the predictor's two sym_solve calls share one).
+// Reductions are fixed-order: results are bitwise reproducible.
 #include "lpipm_internal.hpp"
 
 namespace lpipm {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
+// ------------------------------------------------------------------------------------------------
+// plan: storage + static descriptors of the merge GEMMs
+double* FactorPlan::blk_inv(int k) const {
+    const int r = k * NB;
+    for (const SuperBlock& s : sbs)
+        if (r >= s.row0 && r < s.row0 + s.size) return s.inv + (size_t)(r - s.row0) * s.size + (r - s.row0);
+    return nullptr;
+}
+double* FactorPlan::blk_invT(int k) const {
+    const int r = k * NB;
+    for (const SuperBlock& s : sbs)
+        if (r >= s.row0 && r < s.row0 + s.size) return s.invT + (size_t)(r - s.row0) * s.size + (r - s.row0);
+    return nullptr;
+}
+int FactorPlan::blk_ld(int k) const {
+    const int r = k * NB;
+    for (const SuperBlock& s : sbs)
+        if (r >= s.row0 && r < s.row0 + s.size) return s.size;
+    return 0;
+}
 
-// out[r] (+)= sum_c B[r][c] * x[c] for a dense 128x128 row-major block (ld), rows split over the 4
-// waves (32 each); a wave reads one full row per instruction (64 lanes x 16 B) and butterfly-reduces.
-// xs: x in LDS [nrhs][128].  result for row r delivered to lane 0 of the wave -> res(r, rhs, value).
-template <int NRHS, typename F>
-__device__ __forceinline__ void block_matvec_n(const double* __restrict__ B, long long ld,
-                                               const double (*xs)[NB], int wave, int lane, F&& res) {
-    d2 xv[NRHS];
-#pragma unroll
-    for (int q = 0; q < NRHS; ++q) xv[q] = *(const d2*)&xs[q][2 * lane];
-#pragma unroll 4
-    for (int rr = 0; rr < 32; ++rr) {
-        const int r = wave * 32 + rr;
-        const d2 bv = *(const d2*)(B + (long long)r * ld + 2 * lane);
-        double acc[NRHS];
-#pragma unroll
-        for (int q = 0; q < NRHS; ++q) acc[q] = bv[0] * xv[q][0] + bv[1] * xv[q][1];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-            for (int q = 0; q < NRHS; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NRHS; ++q) res(r, q, acc[q]);
+namespace {
+struct Merge { int sb, lo, mid, hi, level; size_t toff; };   // block indices local to the super-block
+
+// inverse of blocks [lo, hi) from the inverses of [lo, mid) and [mid, hi); returns its level
+int plan_merges(int sb, int lo, int hi, std::vector<Merge>& out, size_t& tcursor) {
+    if (hi - lo <= 1) return 0;
+    int p = 1;
+    while (p * 2 < hi - lo) p *= 2;   // left part: largest power of two below the width
+    const int mid = lo + p;
+    const int l1 = plan_merges(sb, lo, mid, out, tcursor);
+    const int l2 = plan_merges(sb, mid, hi, out, tcursor);
+    const int lvl = (l1 > l2 ? l1 : l2) + 1;
+    out.push_back(Merge{sb, lo, mid, hi, lvl, tcursor});
+    tcursor += (size_t)(mid - lo) * NB * (size_t)(hi - mid) * NB;
+    return lvl;
+}
+}  // namespace
+
+hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, hipStream_t st) {
+    factor_plan_destroy(plan);
+    plan.mp = mp;
+    hipError_t e;
+    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
+        hipError_t er = hipMalloc(p, bytes ? bytes : 8);
+        if (er != hipSuccess) return er;
+        plan.allocs.push_back(*p);
+        return hipMemsetAsync(*p, 0, bytes ? bytes : 8, st);
+    };
+    for (int r0 = 0; r0 < mp; r0 += SUPER) {
+        SuperBlock s{};
+        s.row0 = r0;
+        s.size = mp - r0 < SUPER ? mp - r0 : SUPER;
+        if ((e = dalloc((void**)&s.inv, (size_t)s.size * s.size * sizeof(double))) != hipSuccess) return e;
+        if ((e = dalloc((void**)&s.invT, (size_t)s.size * s.size * sizeof(double))) != hipSuccess) return e;
+        plan.sbs.push_back(s);
+    }
+    std::vector<Merge> merges;
+    size_t tcursor = 0;
+    int maxlvl = 0;
+    for (size_t i = 0; i < plan.sbs.size(); ++i) {
+        const int lvl = plan_merges((int)i, 0, plan.sbs[i].size / NB, merges, tcursor);
+        if (lvl > maxlvl) maxlvl = lvl;
+    }
+    double* tws = nullptr;
+    if ((e = dalloc((void**)&tws, tcursor * sizeof(double))) != hipSuccess) return e;
+    // slabs of the backward sweep's transposed panel products: (rows below / 128) x 2 rhs x SUPER
+    if ((e = dalloc((void**)&plan.tpart, (size_t)(mp / GEMVT_ROWS + 1) * 2 * SUPER * sizeof(double))) != hipSuccess)
+        return e;
+
+    std::vector<GemmTileDesc> descs;
+    plan.stages.clear();
+    const int KPB = NB / BK;   // k-tiles per 128-block
+    for (int lvl = 1; lvl <= maxlvl; ++lvl) {
+        // stage A: T^T (s1 x s2) = Inv11^T . L21^T ; Inv11^T is upper triangular: k >= row tile
+        const int a0 = (int)descs.size();
+        for (const Merge& m : merges) {
+            if (m.level != lvl) continue;
+            const SuperBlock& s = plan.sbs[m.sb];
+            const int n1 = m.mid - m.lo, n2 = m.hi - m.mid;
+            for (int tj = 0; tj < n1; ++tj)
+                for (int ti = 0; ti < n2; ++ti) {
+                    GemmTileDesc d{};
+                    d.P = s.invT + (size_t)((m.lo + tj) * NB) * s.size + m.lo * NB;
+                    d.ldp = s.size;
+                    d.Q = L + (size_t)(s.row0 + (m.mid + ti) * NB) * ld + s.row0 + m.lo * NB;
+                    d.ldq = (int)ld;
+                    d.C = tws + m.toff + (size_t)(tj * NB) * (n2 * NB) + ti * NB;
+                    d.ldc = n2 * NB;
+                    d.kt_begin = tj * KPB;
+                    d.kt_end = n1 * KPB;
+                    d.alpha = 1.0;
+                    descs.push_back(d);
+                }
+        }
+        plan.stages.push_back({a0, (int)descs.size() - a0});
+        // stage B: Inv21 (s2 x s1) = -Inv22 . T  and its transpose (s1 x s2) = -T^T . Inv22^T ;
+        // Inv22 is lower triangular: k <= row tile of Inv22
+        const int b0 = (int)descs.size();
+        for (const Merge& m : merges) {
+            if (m.level != lvl) continue;
+            const SuperBlock& s = plan.sbs[m.sb];
+            const int n1 = m.mid - m.lo, n2 = m.hi - m.mid;
+            double* TT = tws + m.toff;
+            for (int ti = 0; ti < n2; ++ti)
+                for (int tj = 0; tj < n1; ++tj) {
+                    GemmTileDesc d{};   // Inv21(ti,tj) = -sum_k Inv22[ti][k] T^T[tj][k]
+                    d.P = s.inv + (size_t)((m.mid + ti) * NB) * s.size + m.mid * NB;
+                    d.ldp = s.size;
+                    d.Q = TT + (size_t)(tj * NB) * (n2 * NB);
+                    d.ldq = n2 * NB;
+                    d.C = s.inv + (size_t)((m.mid + ti) * NB) * s.size + (m.lo + tj) * NB;
+                    d.ldc = s.size;
+                    d.kt_begin = 0;
+                    d.kt_end = (ti + 1) * KPB;
+                    d.alpha = -1.0;
+                    descs.push_back(d);
+                    GemmTileDesc t{};   // Inv21^T(tj,ti) = -sum_k T^T[tj][k] Inv22[ti][k]
+                    t.P = TT + (size_t)(tj * NB) * (n2 * NB);
+                    t.ldp = n2 * NB;
+                    t.Q = s.inv + (size_t)((m.mid + ti) * NB) * s.size + m.mid * NB;
+                    t.ldq = s.size;
+                    t.C = s.invT + (size_t)((m.lo + tj) * NB) * s.size + (m.mid + ti) * NB;
+                    t.ldc = s.size;
+                    t.kt_begin = 0;
+                    t.kt_end = (ti + 1) * KPB;
+                    t.alpha = -1.0;
+                    descs.push_back(t);
+                }
+        }
+        plan.stages.push_back({b0, (int)descs.size() - b0});
+    }
+    if ((e = dalloc((void**)&plan.descs_dev, descs.size() * sizeof(GemmTileDesc))) != hipSuccess) return e;
+    if (!descs.empty()) {
+        e = hipMemcpyAsync(plan.descs_dev, descs.data(), descs.size() * sizeof(GemmTileDesc), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipStreamSynchronize(st);   // `descs` must outlive the copy
+}
+
+void factor_plan_destroy(FactorPlan& plan) {
+    for (void* p : plan.allocs) (void)hipFree(p);
+    plan.allocs.clear();
+    plan.sbs.clear();
+    plan.stages.clear();
+    plan.descs_dev = nullptr;
+    plan.tpart = nullptr;
+    plan.mp = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[q][c] -= sum_s part[s][q][c]   (c < width): folds the row-split slabs of the transposed panel
+// product into the right-hand side of the backward step, in slab order.
+__global__ __launch_bounds__(256) void trsv_fold_kernel(double* __restrict__ y, long long ldy,
+                                                        const double* __restrict__ part, int nsplit, int nrhs,
+                                                        int width) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    for (int q = 0; q < nrhs; ++q) {
+        double s = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) s += part[((long long)sp * nrhs + q) * width + c];
+        y[(long long)q * ldy + c] -= s;
+    }
+}
+
+hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan, int nrhs, double* R,
+                             double* Y, hipStream_t st) {
+    const int mp = plan.mp;
+    hipError_t e;
+    const int nsb = (int)plan.sbs.size();
+    // forward: L y = r
+    for (int k = 0; k < nsb; ++k) {
+        const SuperBlock& s = plan.sbs[k];
+        e = launch_gemv_n(s.inv, s.size, s.size, s.size, nrhs, R + s.row0, mp, nullptr, nullptr, Y + s.row0, mp, st);
+        if (e != hipSuccess) return e;
+        const int below = mp - (s.row0 + s.size);
+        if (below > 0) {
+            double* rb = R + s.row0 + s.size;
+            e = launch_gemv_n(L + (size_t)(s.row0 + s.size) * ld + s.row0, ld, below, s.size, nrhs, Y + s.row0, mp, rb,
+                              rb + mp, rb, mp, st, -1.0);
+            if (e != hipSuccess) return e;
         }
     }
-}
-
-// part[wave][q][c] = sum_{r in wave's 32 rows} B[r][c] * x[q][r]  (transposed product, lanes over c)
-template <int NRHS>
-__device__ __forceinline__ void block_matvec_t(const double* __restrict__ B, long long ld,
-                                               const double (*xs)[NB], int wave, int lane,
-                                               double (*part)[NRHS][NB]) {
-    d2 acc[NRHS];
-#pragma unroll
-    for (int q = 0; q < NRHS; ++q) acc[q] = (d2){0.0, 0.0};
-#pragma unroll 4
-    for (int rr = 0; rr < 32; ++rr) {
-        const int r = wave * 32 + rr;
-        const d2 bv = *(const d2*)(B + (long long)r * ld + 2 * lane);
-#pragma unroll
-        for (int q = 0; q < NRHS; ++q) acc[q] += bv * xs[q][r];
-    }
-#pragma unroll
-    for (int q = 0; q < NRHS; ++q) *(d2*)&part[wave][q][2 * lane] = acc[q];
-}
-
-// Forward step k.  grid = nb - k: workgroup w handles block row i = k + w.
-//   R : right-hand sides, updated in place for rows below block k   [nrhs][mp]
-//   Y : forward solution                                             [nrhs][mp]
-template <int NRHS>
-__global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ L, long long ld,
-                                                     const double* __restrict__ invL, int mp, int k,
-                                                     double* __restrict__ R, double* __restrict__ Y) {
-    __shared__ __attribute__((aligned(16))) double bs[NRHS][NB];
-    __shared__ __attribute__((aligned(16))) double ys[NRHS][NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = k + blockIdx.x;
-    for (int e = tid; e < NRHS * NB; e += 256) bs[e / NB][e % NB] = R[(long long)(e / NB) * mp + k * NB + e % NB];
-    __syncthreads();
-    block_matvec_n<NRHS>(invL + (long long)k * NB * NB, NB, bs, wave, lane,
-                         [&](int r, int q, double v) { ys[q][r] = v; });
-    __syncthreads();
-    if (i == k) {
-        for (int e = tid; e < NRHS * NB; e += 256) Y[(long long)(e / NB) * mp + k * NB + e % NB] = ys[e / NB][e % NB];
-    } else {
-        const double* blk = L + (long long)i * NB * ld + (long long)k * NB;
-        block_matvec_n<NRHS>(blk, ld, ys, wave, lane, [&](int r, int q, double v) {
-            R[(long long)q * mp + i * NB + r] -= v;
-        });
-    }
-}
-
-// Backward step k.  grid = k + 1: workgroup w < k handles column block j = w, workgroup k writes v_k.
-//   Y : forward solution, updated in place for blocks above k      [nrhs][mp]
-//   V : final solution                                              [nrhs][mp]
-template <int NRHS>
-__global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, long long ld,
-                                                     const double* __restrict__ invL, int mp, int k,
-                                                     double* __restrict__ Y, double* __restrict__ V) {
-    __shared__ __attribute__((aligned(16))) double bs[NRHS][NB];
-    __shared__ __attribute__((aligned(16))) double vs[NRHS][NB];
-    __shared__ __attribute__((aligned(16))) double part[4][NRHS][NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = blockIdx.x;
-    for (int e = tid; e < NRHS * NB; e += 256) bs[e / NB][e % NB] = Y[(long long)(e / NB) * mp + k * NB + e % NB];
-    __syncthreads();
-    block_matvec_t<NRHS>(invL + (long long)k * NB * NB, NB, bs, wave, lane, part);
-    __syncthreads();
-    for (int e = tid; e < NRHS * NB; e += 256) {
-        const int q = e / NB, c = e % NB;
-        vs[q][c] = (part[0][q][c] + part[1][q][c]) + (part[2][q][c] + part[3][q][c]);
-    }
-    __syncthreads();
-    if (j == k) {
-        for (int e = tid; e < NRHS * NB; e += 256) V[(long long)(e / NB) * mp + k * NB + e % NB] = vs[e / NB][e % NB];
-    } else {
-        const double* blk = L + (long long)k * NB * ld + (long long)j * NB;
-        block_matvec_t<NRHS>(blk, ld, vs, wave, lane, part);
-        __syncthreads();
-        for (int e = tid; e < NRHS * NB; e += 256) {
-            const int q = e / NB, c = e % NB;
-            Y[(long long)q * mp + j * NB + c] -= (part[0][q][c] + part[1][q][c]) + (part[2][q][c] + part[3][q][c]);
+    // backward: L^T v = y   (solution written over R)
+    for (int k = nsb - 1; k >= 0; --k) {
+        const SuperBlock& s = plan.sbs[k];
+        const int below = mp - (s.row0 + s.size);
+        if (below > 0) {
+            e = launch_gemv_t(L + (size_t)(s.row0 + s.size) * ld + s.row0, ld, below, s.size, nrhs,
+                              R + s.row0 + s.size, mp, plan.tpart, st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(trsv_fold_kernel, dim3((s.size + 255) / 256), dim3(256), 0, st, Y + s.row0,
+                               (long long)mp, plan.tpart, below / GEMVT_ROWS, nrhs, s.size);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
         }
+        e = launch_gemv_n(s.invT, s.size, s.size, s.size, nrhs, Y + s.row0, mp, nullptr, nullptr, R + s.row0, mp, st);
+        if (e != hipSuccess) return e;
     }
-}
-
-// R is consumed (overwritten: first as forward scratch, finally with the solution).
-// Yscratch: nrhs x mp doubles of workspace.
-hipError_t launch_chol_solve_ws(const double* L, int64_t ld, const double* invL, int mp, int nrhs,
-                                double* R, double* Yscratch, hipStream_t st) {
-    const int nb = mp / NB;
-    for (int k = 0; k < nb; ++k) {
-        if (nrhs == 1)
-            hipLaunchKernelGGL(trsv_fwd_step<1>, dim3(nb - k), dim3(256), 0, st, L, (long long)ld, invL, mp, k, R, Yscratch);
-        else
-            hipLaunchKernelGGL(trsv_fwd_step<2>, dim3(nb - k), dim3(256), 0, st, L, (long long)ld, invL, mp, k, R, Yscratch);
-    }
-    for (int k = nb - 1; k >= 0; --k) {
-        if (nrhs == 1)
-            hipLaunchKernelGGL(trsv_bwd_step<1>, dim3(k + 1), dim3(256), 0, st, L, (long long)ld, invL, mp, k, Yscratch, R);
-        else
-            hipLaunchKernelGGL(trsv_bwd_step<2>, dim3(k + 1), dim3(256), 0, st, L, (long long)ld, invL, mp, k, Yscratch, R);
-    }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace lpipm

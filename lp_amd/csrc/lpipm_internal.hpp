@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
+#include <vector>
+#include <utility>
 #include "../../include/lpipm.h"
 
 namespace lpipm {
@@ -46,28 +48,65 @@ struct GemmArgs {
     int           diag_pad_from;// rows/cols >= this on the diagonal are written as 1.0 (-1: off)
     double*       ws;           // stream-K partial slabs: 2 per workgroup, TILE*TILE doubles each
     int           nwg;          // workgroups launched (== grid); ntiles*KT split evenly
+    int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
 };
 // Launches the main kernel and, when the k-range of a tile is split over workgroups, the
 // deterministic fix-up pass.  ws must hold 2*nwg slabs when nwg != ntiles.
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st);
+// One 128x128 output tile of a grouped launch: C = alpha * P[0:128, kb:ke) . Q[0:128, kb:ke)^T
+// (k-range in units of BK), each tile with its own operands.
+struct GemmTileDesc {
+    const double* P; const double* Q; double* C;
+    int ldp, ldq, ldc;
+    int kt_begin, kt_end;
+    double alpha;
+};
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st);
 // Workgroup count the stream-K ADA^T launch wants for ntiles x KT work.
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 
+// ---------------------------------------------------------------- factor plan (kernels_trsv.hip)
+// The factor L is consumed through explicit inverses of its diagonal SUPER-blocks (up to 1024 wide):
+// a triangular solve is then a handful of fully parallel mat-vec launches instead of mp/128
+// serialized block steps.  The plan owns the inverse storage and the static launch descriptors.
+constexpr int SUPER = 1024;  // super-block width (multiple of NB)
+struct SuperBlock {
+    int row0, size;          // first row/column of the diagonal super-block, its width (multiple of NB)
+    double* inv;             // size x size row-major: inv(L_ss)   (lower triangular, zeros above)
+    double* invT;            // size x size row-major: inv(L_ss)^T (upper triangular, zeros below)
+};
+struct FactorPlan {
+    int mp = 0;
+    std::vector<SuperBlock> sbs;
+    std::vector<void*> allocs;                   // device memory owned by the plan
+    GemmTileDesc* descs_dev = nullptr;           // grouped-GEMM tiles of all merge stages
+    std::vector<std::pair<int, int>> stages;     // (first descriptor, count) per launch, in order
+    double* tpart = nullptr;                     // gemv_t slabs of the backward sweep
+    // 128-block k of the factorisation -> where its inverse / transposed inverse go, and their ld
+    double* blk_inv(int k) const;
+    double* blk_invT(int k) const;
+    int blk_ld(int k) const;
+};
+// Allocates inverse storage for an mp x mp factor living at (L, ld) and builds the descriptors.
+hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, hipStream_t st);
+void factor_plan_destroy(FactorPlan& plan);
+
 // ---------------------------------------------------------------- Cholesky (kernels_potrf.hip)
-// In-place blocked lower Cholesky of the mp x mp row-major matrix M (mp multiple of NB).
-// invL receives the inverse of every NB x NB diagonal block of L (mp/NB slabs, row-major).
-// info (device int32): 0, or 1 + index of the first non-positive pivot.
-hipError_t launch_potrf(double* M, int64_t ld, int mp, double* invL, int32_t* info, hipStream_t st);
+// In-place blocked lower Cholesky of the mp x mp row-major matrix M (mp multiple of NB), followed by
+// the inverses of the diagonal super-blocks (plan).  info (device int32): 0, or 1 + index of the
+// first non-positive pivot.
+hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st);
 
 // ---------------------------------------------------------------- triangular solves (kernels_trsv.hip)
-// In place: R[r] <- L^-T L^-1 R[r], r < nrhs (1|2); R is nrhs x mp (row stride mp).
-// (solve launcher with workspace: vec_kernels.hpp, launch_chol_solve_ws)
+// R[r] <- L^-T L^-1 R[r], r < nrhs (1|2); R is nrhs x mp (row stride mp); Yscratch: nrhs x mp.
+hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan, int nrhs, double* R,
+                             double* Yscratch, hipStream_t st);
 
 // ---------------------------------------------------------------- GEMV (kernels_gemv.hip)
-// Y[r][i] = (add[r] ? add[r][i] : 0) + sum_k A[i][k] * W[r][k],   i < m (rows of the padded A)
+// Y[r][i] = (add[r] ? add[r][i] : 0) + alpha * sum_k A[i][k] * W[r][k],   i < m, k < np
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
-                         hipStream_t st);
+                         hipStream_t st, double alpha = 1.0);
 // Upart[s][r][k] = sum_{i in row split s} A[i][k] * V[r][i];  consumers sum the splits in order.
 constexpr int GEMVT_ROWS = 128;
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,

@@ -46,13 +46,14 @@ struct lpipm_ctx {
     std::vector<size_t> alloc_bytes;
     std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
     // problem + state + work
-    double *A = nullptr, *M = nullptr, *invL = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
+    FactorPlan plan, kplan;
+    double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
     int2* tile_list = nullptr;
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
     StatusRec* status_host = nullptr;  // pinned
     // stand-alone potrf/solve buffers
-    double *kM = nullptr, *kM0 = nullptr, *kinvL = nullptr, *kR = nullptr, *kY = nullptr;
+    double *kM = nullptr, *kM0 = nullptr, *kR = nullptr, *kY = nullptr;
     int32_t* kinfo = nullptr;
     int kmp = 0;
     // profiling
@@ -193,6 +194,8 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     free_list(c->allocs);
     free_list(c->kallocs);
+    factor_plan_destroy(c->plan);
+    factor_plan_destroy(c->kplan);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
@@ -225,6 +228,7 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
     if (!c->has_problem || mp != c->mp || np != c->np) {
         LP_HIP(hipStreamSynchronize(c->st));
         free_list(c->allocs);
+        factor_plan_destroy(c->plan);
         c->alloc_bytes.clear();
         c->has_problem = false;
         c->mp = mp; c->np = np;
@@ -253,7 +257,7 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
         LP_TRY(dalloc(L, &c->alloc_bytes, &v.status, 1, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.flags, 1, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->M, (size_t)mp * mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->invL, (size_t)(mp / NB) * NB * NB, st));
+        LP_HIP(factor_plan_create(c->plan, c->M, mp, mp, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->xout, (size_t)np, st));
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
@@ -314,12 +318,12 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_VEC);
     LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
     prof_mark(c, T_ADAT);
-    LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->invL, v.potrf_info, st));   // :129-131
+    LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
     LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 2, v.W, c->np, v.b, v.rP, v.R, c->mp, st));  // :220
     prof_mark(c, T_GEMV);
-    LP_HIP(launch_chol_solve_ws(c->M, c->mp, c->invL, c->mp, 2, v.R, c->Y, st));                     // :221
+    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));                     // :221
     prof_mark(c, T_TRSV);
     LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 2, v.R, c->mp, c->ATpart, st));                  // :223
     prof_mark(c, T_GEMV);
@@ -330,7 +334,7 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     // corrector: only the second sym_solve changes
     LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 1, v.W, c->np, v.rP2, nullptr, v.R, c->mp, st));
     prof_mark(c, T_GEMV);
-    LP_HIP(launch_chol_solve_ws(c->M, c->mp, c->invL, c->mp, 1, v.R, c->Y, st));
+    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
     prof_mark(c, T_TRSV);
     LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 1, v.R, c->mp, c->ATpart, st));
     prof_mark(c, T_GEMV);
@@ -502,13 +506,14 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     if (c->kmp == mp) return LPIPM_OK;
     LP_HIP(hipStreamSynchronize(c->st));
     free_list(c->kallocs);
+    factor_plan_destroy(c->kplan);
     c->kmp = 0;
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kM, (size_t)mp * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kM0, (size_t)mp * mp, c->st));
-    LP_TRY(dalloc(c->kallocs, nullptr, &c->kinvL, (size_t)(mp / NB) * NB * NB, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kR, (size_t)2 * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kY, (size_t)2 * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, c->st));
     c->kmp = mp;
     return LPIPM_OK;
 }
@@ -533,7 +538,7 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
     for (int r = 0; r < repeats; ++r) {
         LP_HIP(hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st));
         LP_HIP(hipEventRecord(c->ev_begin, c->st));
-        LP_HIP(launch_potrf(c->kM, mp, mp, c->kinvL, c->kinfo, c->st));
+        LP_HIP(launch_potrf(c->kM, mp, mp, c->kplan, c->kinfo, c->st));
         LP_HIP(hipEventRecord(c->ev_end, c->st));
         LP_HIP(hipStreamSynchronize(c->st));
         float ms = 0.f;
@@ -546,7 +551,7 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
         if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
             g_diag_stamps = d;
             (void)hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st);
-            (void)launch_potrf(c->kM, mp, mp, c->kinvL, c->kinfo, c->st);
+            (void)launch_potrf(c->kM, mp, mp, c->kplan, c->kinfo, c->st);
             (void)hipStreamSynchronize(c->st);
             g_diag_stamps = nullptr;
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
@@ -579,7 +584,7 @@ extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const doub
         LP_HIP(hipMemcpy2DAsync(c->kR, (size_t)mp * sizeof(double), R, m * sizeof(double), m * sizeof(double), nrhs,
                                 hipMemcpyHostToDevice, c->st));
         LP_HIP(hipEventRecord(c->ev_begin, c->st));
-        LP_HIP(launch_chol_solve_ws(c->kM, mp, c->kinvL, mp, nrhs, c->kR, c->kY, c->st));
+        LP_HIP(launch_chol_solve(c->kM, mp, c->kplan, nrhs, c->kR, c->kY, c->st));
         LP_HIP(hipEventRecord(c->ev_end, c->st));
         LP_HIP(hipStreamSynchronize(c->st));
         float ms = 0.f;

@@ -49,7 +49,5 @@ void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
 void vec_step(const VecArgs& a, int ip, hipStream_t st);
 void vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st);
 
-hipError_t launch_chol_solve_ws(const double* L, int64_t ld, const double* invL, int mp, int nrhs,
-                                double* R, double* Yscratch, hipStream_t st);
 
 }  // namespace lpipm
