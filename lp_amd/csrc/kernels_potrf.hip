@@ -55,111 +55,239 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 // 16x16 MFMA tiles on the LDS image (v_mfma_f64_16x16x4_f64: A lane l = A[l&15][k=l>>4],
 // B lane l = B[k=l>>4][n=l&15], C/D reg r = C[(l>>4)+4r][l&15]).  With row stride 130 the
 // A-form fragment read (16 rows x 2 k per 32-lane LDS phase) is bank-conflict free.
-//   acc += sign * sum_{k<4*ksteps} X[ar+i][ac+k] * Y[br+j][bc+k]          ("NT": both K-contiguous)
-__device__ __forceinline__ d4 mfma_nt16(d4 acc, const double (*Ls)[LS], int ar, int ac, int br, int bc,
-                                        int ksteps, double sign, int fr, int fq) {
-    for (int q = 0; q < ksteps; ++q) {
-        const double a = sign * Ls[ar + fr][ac + 4 * q + fq];
-        const double b = Ls[br + fr][bc + 4 * q + fq];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-//   acc += sum_{k<4*ksteps} X[ar+i][ac+k] * Y[br+k][bc+j]                  ("NN")
-__device__ __forceinline__ d4 mfma_nn16(d4 acc, const double (*Ls)[LS], int ar, int ac, int br, int bc,
-                                        int ksteps, int fr, int fq) {
-    for (int q = 0; q < ksteps; ++q) {
-        const double a = Ls[ar + fr][ac + 4 * q + fq];
-        const double b = Ls[br + 4 * q + fq][bc + fr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __forceinline__ void store_tile16(double (*Ls)[LS], int r0, int c0, d4 v, double sign, int fr, int fq) {
+// Mblk: top-left of the 128x128 diagonal block (row-major, ld).  Linv / LinvT: where inv(L_kk) and
+// its transpose go (row-major, ldinv): the diagonal 128-blocks of the super-block inverses.
+//
+// ONE elimination produces both the factor and its inverse.  Right-looking Cholesky applied to the
+// augmented matrix [A; I] leaves [L; L^-T]: the extra identity rows are just more panel rows of the
+// triangular solve X.L^T = B with B = I.  Row i of L^-T is zero left of column i, so its entries live
+// in the (otherwise unused) strict upper triangle of the LDS image; the diagonal 1/L_ii goes to dinv.
+//
+// 8 block columns of 16.  For each, three waves eliminate the 16 columns on 144 rows held one per
+// lane: lanes 0-15 of every wave replicate the 16 diagonal rows (no wave waits on another), lanes
+// 16-63 carry the 128 other rows (panel rows below, identity rows above / inside the block).  Per
+// pivot the critical chain is: v_readlane of pivot + two multipliers -> Newton reciprocal -> fma on
+// the next pivot column; the rest of the column is broadcast through LDS one step later and the
+// 1/sqrt scaling of finished columns is off the chain.  Then one rank-16 update of everything to
+// the right (lower tiles of A and the identity rows' tiles in the upper triangle) as 16x16 MFMA
+// tiles, two independent tiles in flight per wave.
+// Barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the fire-and-forget global stores of finished L columns (thousands of cycles per block column).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int XS = SB + 2;   // row stride of the compact identity-row operand (conflict-free MFMA reads)
+
+// Eliminates block column jb (16 columns starting at c0) on 144 rows, one per lane of waves 0..2.
+// xidb: where the eliminated NEW identity rows go as an MFMA operand.
+__device__ __forceinline__ void eliminate_block_column(double (*Ls)[LS], double (*xidb)[XS], double (*scrw)[SB],
+                                                       double* dinv, int jb, int wave, int lane, int32_t* info,
+                                                       int global_row0, double* __restrict__ Mblk, long long ld) {
+    const int c0 = jb * SB;
+    const int npanel = NB - c0 - SB;                        // rows of A below the diagonal sub-block
+    const bool is_diag = lane < SB;
+    // non-diagonal rows: v in [0,128): panel rows first, then identity rows 0 .. c0+15
+    const int v = wave * 48 + (lane - SB);
+    const bool valid = is_diag || v < NB;
+    const bool is_panel = !is_diag && v < npanel;
+    const int idrow = v - npanel;                           // identity row index (when !is_panel)
+    const bool is_newid = !is_diag && !is_panel && idrow >= c0;
+    const int row = is_diag ? c0 + lane : (is_panel ? c0 + SB + v : (valid ? idrow : 0));
+    double a[SB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ls[r0 + fq + 4 * r][c0 + fr] = sign * v[r];
+    for (int c = 0; c < SB; c += 2) {
+        const d2 x = *(const d2*)&Ls[row][c0 + c];
+        a[c] = x[0]; a[c + 1] = x[1];
+    }
+    if (is_newid) {                                         // e_i restricted to this block's columns
+#pragma unroll
+        for (int c = 0; c < SB; ++c) a[c] = (c == idrow - c0) ? 1.0 : 0.0;
+    }
+    // Chain-critical values travel by v_readlane: the pivot a[j] of lane j and the first two
+    // multipliers (a[j] of lanes j+1, j+2).  The rest of column j goes through LDS: its reads are
+    // issued at the top of step j and consumed at the bottom, after the reciprocal chain, so the
+    // LDS round trip overlaps the chain (a wave issues in order).
+    double piv = readlane_f64(a[0], 0);
+    double c1 = readlane_f64(a[0], 1), c2 = readlane_f64(a[0], 2);
+    if (is_diag) scrw[0][lane] = a[0];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        __builtin_amdgcn_wave_barrier();
+        double col[SB];
+#pragma unroll
+        for (int k = (j + 3) & ~1; k < SB; k += 2) {
+            const d2 x = *(const d2*)&scrw[j & 1][k];
+            col[k] = x[0]; col[k + 1] = x[1];
+        }
+        const double rinv = rcp_nr(piv);
+        const double t = a[j] * rinv;
+        double piv_next = 0.0, c1_next = 0.0, c2_next = 0.0;
+        if (j + 1 < SB) {
+            a[j + 1] = fma(-t, c1, a[j + 1]);
+            piv_next = readlane_f64(a[j + 1], j + 1);
+            if (j + 2 < SB) c1_next = readlane_f64(a[j + 1], j + 2);
+            if (j + 3 < SB) c2_next = readlane_f64(a[j + 1], j + 3);
+            if (is_diag) scrw[(j + 1) & 1][lane] = a[j + 1];
+        }
+        if (j + 2 < SB) a[j + 2] = fma(-t, c2, a[j + 2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = j + 3; k < SB; ++k) a[k] = fma(-t, col[k], a[k]);
+#pragma unroll
+        for (int k = j + 2; k < SB; ++k) asm volatile("" : "+v"(a[k]));   // keep the update eager
+        piv = piv_next; c1 = c1_next; c2 = c2_next;
+    }
+    // finished columns: scale column j by 1/sqrt(pivot j).  Lane j of the diagonal rows still holds
+    // pivot j in a[j]: it forms the rsqrt, all lanes pick the 16 values up from LDS.
+    {
+        double mine = a[0];
+#pragma unroll
+        for (int j = 1; j < SB; ++j) mine = (lane == j) ? a[j] : mine;
+        const unsigned long long bad = __ballot(is_diag && !(mine > 0.0));
+        if (bad != 0ull && wave == 0 && lane == 0)   // lowest set bit = first bad pivot of this block column
+            atomicCAS((int*)info, 0, global_row0 + c0 + (int)__ffsll((long long)bad));
+        const double myrs = rsqrt_nr(mine);
+        __builtin_amdgcn_wave_barrier();
+        if (is_diag) {
+            scrw[0][lane] = myrs;
+            if (wave == 0) dinv[c0 + lane] = myrs;          // 1/L_ii = 1/sqrt(pivot)
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < SB; j += 2) {
+            const d2 rs = *(const d2*)&scrw[0][j];
+            a[j] *= rs[0]; a[j + 1] *= rs[1];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // write back.  Diagonal rows (wave 0 only; replicas are identical): nothing reads the factored
+    // diagonal sub-block from LDS again, so it goes straight to global memory -- and the LDS copy
+    // stays as loaded, which keeps the other waves' replica loads race-free.
+    // Panel / old identity rows: all 16 columns.  New identity rows: row q of inv(L16)^T goes to xidb
+    // (MFMA operand, zeros kept) and its strictly-upper part into the diagonal sub-block.
+    if (is_diag) {
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < SB; ++c)
+                if (c <= lane) Mblk[(long long)row * ld + c0 + c] = a[c];
+        }
+    } else if (valid) {
+        if (is_newid) {
+            const int q = idrow - c0;
+#pragma unroll
+            for (int c = 0; c < SB; c += 2) *(d2*)&xidb[q][c] = (d2){a[c], a[c + 1]};
+#pragma unroll
+            for (int c = 0; c < SB; ++c)
+                if (c > q) Ls[row][c0 + c] = a[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < SB; c += 2) *(d2*)&Ls[row][c0 + c] = (d2){a[c], a[c + 1]};
+        }
+    }
 }
 
-// One doubling level of the triangular inverse, block size S -> 2S, all pairs at once:
-//   Inv21 = -Inv22 . (L21 . Inv11)   (16x16 MFMA tiles; zero blocks of the triangular factors
-//   are skipped; the result replaces L21 in place, so each product is computed into registers,
-//   then written after a barrier).
-template <int S>
-__device__ __forceinline__ void trtri_level(double (*Ls)[LS], int wave, int fr, int fq) {
-    constexpr int NPAIR = NB / (2 * S);
-    constexpr int TB = S / SB;                  // 16-tiles per block edge
-    constexpr int NT = NPAIR * TB * TB;         // output tiles of the level
-    constexpr int PER = (NT + 7) / 8;           // tiles per wave (8 waves)
-    d4 acc[PER];
-    // phase 1: T = L21 . Inv11  -> T(ti,tj) = sum_{tk >= tj} L21(ti,tk) Inv11(tk,tj)
+// Rank-16 update by block column jb of the tiles right of it:
+//   lower tiles  C(bi,bk) -= X(bi).X(bk)^T    (blocks below the diagonal one, bk <= bi)
+//   upper tiles  U(ib,bk) -= Xid(ib).X(bk)^T  (identity rows ib <= jb; ib == jb reads xidb)
+// `priority`: only the tiles of the next block column (bk == 0), one per wave `w` of `nw`;
+// otherwise all the other tiles (bk >= 1), two independent tiles in flight per wave.
+__device__ __forceinline__ void update_tiles(double (*Ls)[LS], const double (*xidb)[XS], int jb, bool priority,
+                                             int w, int nw, int fr, int fq) {
+    const int c0 = jb * SB, base = c0 + SB;
+    const int nb16 = (NB - base) / SB;
+    // tile list of this phase, indexed 0..count-1
+    //   priority: [0, nb16) lower (bi = t, bk = 0); [nb16, nb16 + jb + 1) upper (ib = t - nb16, bk = 0)
+    //   rest:     lower tiles with bk >= 1: nb16*(nb16-1)/2; upper: (jb+1)*(nb16-1)
+    const int nlow = priority ? nb16 : nb16 * (nb16 - 1) / 2;
+    const int count = priority ? nb16 + jb + 1 : nlow + (jb + 1) * (nb16 - 1);
+    auto decode = [&](int t, int& crow, int& ccol, const double*& ap, int& astride) {
+        if (t < nlow) {
+            int bi, bk;
+            if (priority) { bi = t; bk = 0; }
+            else {          // pairs 1 <= bk <= bi < nb16, row-major over bi
+                bi = 1;
+                while (bi * (bi + 1) / 2 <= t) ++bi;
+                bk = t - bi * (bi - 1) / 2 + 1;
+            }
+            crow = base + SB * bi; ccol = base + SB * bk;
+            ap = &Ls[crow][c0]; astride = LS;
+        } else {
+            const int u = t - nlow;
+            int ib, bk;
+            if (priority) { ib = u; bk = 0; }
+            else { ib = u / (nb16 - 1); bk = u - ib * (nb16 - 1) + 1; }
+            crow = SB * ib; ccol = base + SB * bk;
+            if (ib == jb) { ap = &xidb[0][0]; astride = XS; }
+            else          { ap = &Ls[crow][c0]; astride = LS; }
+        }
+    };
+    for (int t0 = w; t0 < count; t0 += 2 * nw) {
+        const int t1 = t0 + nw;
+        const bool has1 = t1 < count;
+        int r0_, q0_, s0_, r1_ = 0, q1_ = 0, s1_ = LS;
+        const double *ap0, *ap1 = &Ls[0][0];
+        decode(t0, r0_, q0_, ap0, s0_);
+        if (has1) decode(t1, r1_, q1_, ap1, s1_);
+        d4 ca, cb = (d4){0.0, 0.0, 0.0, 0.0};
+        double fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
-    for (int w = 0; w < PER; ++w) {
-        const int t = wave + 8 * w;
-        acc[w] = (d4){0.0, 0.0, 0.0, 0.0};
-        if (t < NT) {
-            const int pair = t / (TB * TB), ti = (t / TB) % TB, tj = t % TB;
-            const int base = pair * 2 * S;
-            acc[w] = mfma_nn16(acc[w], Ls, base + S + ti * SB, base + tj * SB, base + tj * SB, base + tj * SB,
-                               4 * (TB - tj), fr, fq);
+        for (int r = 0; r < 4; ++r) ca[r] = Ls[r0_ + fq + 4 * r][q0_ + fr];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            fa0[u] = -ap0[fr * s0_ + 4 * u + fq];
+            fb0[u] = Ls[q0_ + fr][c0 + 4 * u + fq];
+        }
+        if (has1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cb[r] = Ls[r1_ + fq + 4 * r][q1_ + fr];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                fa1[u] = -ap1[fr * s1_ + 4 * u + fq];
+                fb1[u] = Ls[q1_ + fr][c0 + 4 * u + fq];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { fa1[u] = 0.0; fb1[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ca = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[u], fb0[u], ca, 0, 0, 0);
+            if (has1) cb = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[u], fb1[u], cb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ls[r0_ + fq + 4 * r][q0_ + fr] = ca[r];
+        if (has1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ls[r1_ + fq + 4 * r][q1_ + fr] = cb[r];
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < PER; ++w) {
-        const int t = wave + 8 * w;
-        if (t < NT) {
-            const int pair = t / (TB * TB), ti = (t / TB) % TB, tj = t % TB;
-            const int base = pair * 2 * S;
-            store_tile16(Ls, base + S + ti * SB, base + tj * SB, acc[w], 1.0, fr, fq);
-        }
-    }
-    __syncthreads();
-    // phase 2: Inv21 = -Inv22 . T  -> (ti,tj) = -sum_{tk <= ti} Inv22(ti,tk) T(tk,tj)
-#pragma unroll
-    for (int w = 0; w < PER; ++w) {
-        const int t = wave + 8 * w;
-        acc[w] = (d4){0.0, 0.0, 0.0, 0.0};
-        if (t < NT) {
-            const int pair = t / (TB * TB), ti = (t / TB) % TB, tj = t % TB;
-            const int base = pair * 2 * S;
-            acc[w] = mfma_nn16(acc[w], Ls, base + S + ti * SB, base + S, base + S, base + tj * SB,
-                               4 * (ti + 1), fr, fq);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < PER; ++w) {
-        const int t = wave + 8 * w;
-        if (t < NT) {
-            const int pair = t / (TB * TB), ti = (t / TB) % TB, tj = t % TB;
-            const int base = pair * 2 * S;
-            store_tile16(Ls, base + S + ti * SB, base + tj * SB, acc[w], -1.0, fr, fq);
-        }
-    }
-    __syncthreads();
 }
 
 // Mblk: top-left of the 128x128 diagonal block (row-major, ld).  Linv / LinvT: where inv(L_kk) and
 // its transpose go (row-major, ldinv): the diagonal 128-blocks of the super-block inverses.
 //
-// Factorisation: 8 block columns of 16.  For each, every wave eliminates the 16 columns on
-// 64 rows held one per lane: lanes 0-15 replicate the 16 diagonal rows (so no wave waits on
-// another), lanes 16-63 carry panel rows -- the panel's triangular solve is the same elimination
-// and comes for free.  Per pivot the critical chain is: v_readlane of the pivot -> Newton
-// reciprocal -> one fma on the next pivot column -> publish that column to LDS (read back as
-// broadcast by every lane, double-buffered); the 1/sqrt scaling of the finished column is off
-// the chain.  Then a rank-16 update of the trailing lower triangle as 16x16 MFMA tiles.
-// Inverse: the eight 16x16 diagonal factors are inverted in parallel (one wave each), then three
-// doubling levels (16->32->64->128) of Inv21 = -Inv22.L21.Inv11 on MFMA tiles.
+// ONE elimination produces both the factor and its inverse.  Right-looking Cholesky applied to the
+// augmented matrix [A; I] leaves [L; L^-T]: the extra identity rows are just more panel rows of the
+// triangular solve X.L^T = B with B = I.  Row i of L^-T is zero left of column i, so its entries live
+// in the (otherwise unused) strict upper triangle of the LDS image; the diagonal 1/L_ii goes to dinv.
+//
+// 8 block columns of 16.  Each is eliminated by waves 0..2 on 144 rows held one per lane: lanes 0-15
+// of every wave replicate the 16 diagonal rows (no wave waits on another), lanes 16-63 carry the
+// 128 other rows (panel rows below, identity rows above / inside the block).  The rank-16 update of
+// everything to the right runs as 16x16 MFMA tiles and is software-pipelined against the
+// elimination: first the 8 tiles of the NEXT block column (one per wave), barrier, then waves 0..2
+// eliminate that column while waves 3..7 apply the rest of the update.
 __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mblk, long long ld,
                                                         double* __restrict__ Linv, double* __restrict__ LinvT,
                                                         long long ldinv, int32_t* info, int global_row0,
                                                         long long* stamps) {
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = clock64(); } while (0)
     __shared__ __attribute__((aligned(16))) double Ls[NB][LS];            // 133,120 B
-    __shared__ __attribute__((aligned(16))) double scr[DT / 64][2][SB];   // per-wave column scratch
+    __shared__ __attribute__((aligned(16))) double xid[2][SB][XS];        // eliminated NEW identity rows (double-buffered)
+    __shared__ __attribute__((aligned(16))) double scr[3][2][SB];         // per-wave column scratch
+    __shared__ __attribute__((aligned(16))) double dinv[NB];              // 1 / L_ii
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    constexpr int NW = DT / 64;
 
     for (int e = tid * 2; e < NB * NB; e += 2 * DT) {
         const int r = e >> 7, c = e & 127;
@@ -168,149 +296,58 @@ __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mbl
         if (c + 1 > r) v[1] = 0.0;
         *(d2*)&Ls[r][c] = v;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(0);
-    for (int jb = 0; jb < NSB; ++jb) {
+    if (wave < 3) eliminate_block_column(Ls, xid[0], scr[wave], dinv, 0, wave, lane, info, global_row0, Mblk, ld);
+    lds_barrier();
+    STAMP(1);
+    // Everything that becomes final with block column jb -- columns c0..c0+15 of L (below the diagonal
+    // sub-block, which the eliminating wave stored itself), of L^-T (rows 0..c0+15) and rows
+    // c0..c0+15 of L^-1 -- is written out by threads [t0, t0+nt) as fire-and-forget global stores.
+    // Only the triangles that can be non-zero are stored: the other halves of the inverse slabs are
+    // zero from allocation on and nothing ever writes them.
+    auto store_block_column = [&](int jb, int t, int nt) {
         const int c0 = jb * SB;
-        const int npanel = NB - c0 - SB;
-        // ---- fused elimination of block column jb
-        const int prow = c0 + SB + wave * 48 + (lane - SB);       // panel row of lanes 16..63
-        const bool is_diag = lane < SB;
-        const bool wave_has_rows = wave == 0 || wave * 48 < npanel;
-        if (wave_has_rows) {
-            const bool valid = is_diag || prow < NB;
-            const int row = is_diag ? c0 + lane : (valid ? prow : NB - 1);
-            double a[SB];
-#pragma unroll
-            for (int c = 0; c < SB; c += 2) {
-                const d2 v = *(const d2*)&Ls[row][c0 + c];
-                a[c] = v[0]; a[c + 1] = v[1];
-            }
-            // Chain-critical values travel by v_readlane: the pivot a[j] of lane j and the first two
-            // multipliers (a[j] of lanes j+1, j+2).  The rest of column j goes through LDS: its
-            // reads are issued at the top of step j and consumed at the bottom, after the
-            // reciprocal chain, so the LDS round trip overlaps the chain (a wave issues in order).
-            if (jb == 0) STAMP(8);
-            double piv = readlane_f64(a[0], 0);
-            double c1 = readlane_f64(a[0], 1), c2 = readlane_f64(a[0], 2);
-            double pivs[SB];
-            if (is_diag) scr[wave][0][lane] = a[0];
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                __builtin_amdgcn_wave_barrier();
-                double col[SB];
-#pragma unroll
-                for (int k = (j + 3) & ~1; k < SB; k += 2) {
-                    const d2 v = *(const d2*)&scr[wave][j & 1][k];
-                    col[k] = v[0]; col[k + 1] = v[1];
-                }
-                pivs[j] = piv;
-                const double rinv = rcp_nr(piv);
-                const double t = a[j] * rinv;
-                double piv_next = 0.0, c1_next = 0.0, c2_next = 0.0;
-                if (j + 1 < SB) {
-                    a[j + 1] = fma(-t, c1, a[j + 1]);
-                    piv_next = readlane_f64(a[j + 1], j + 1);
-                    if (j + 2 < SB) c1_next = readlane_f64(a[j + 1], j + 2);
-                    if (j + 3 < SB) c2_next = readlane_f64(a[j + 1], j + 3);
-                    if (is_diag) scr[wave][(j + 1) & 1][lane] = a[j + 1];
-                }
-                if (j + 2 < SB) a[j + 2] = fma(-t, c2, a[j + 2]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = j + 3; k < SB; ++k) a[k] = fma(-t, col[k], a[k]);
-#pragma unroll
-                for (int k = j + 2; k < SB; ++k) asm volatile("" : "+v"(a[k]));   // keep the update eager
-                piv = piv_next; c1 = c1_next; c2 = c2_next;
-            }
-            if (jb == 0) STAMP(9);
-            // finished columns of L: scale by 1/sqrt(pivot) (off the chain); first bad pivot -> info
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                if (!(pivs[j] > 0.0) && wave == 0 && lane == 0) atomicCAS((int*)info, 0, global_row0 + c0 + j + 1);
-                a[j] = a[j] * rsqrt_nr(pivs[j]);
-            }
-            if (jb == 0) STAMP(10);
-            // diagonal rows: wave 0 writes (replicas are identical); strict upper part stays zero
-            if (is_diag) {
-                if (wave == 0) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) Ls[row][c0 + c] = (c <= lane) ? a[c] : 0.0;
-                }
-            } else if (valid) {
-#pragma unroll
-                for (int c = 0; c < SB; c += 2) *(d2*)&Ls[row][c0 + c] = (d2){a[c], a[c + 1]};
+        for (int e = t; e < (NB - c0 - SB) * (SB / 2); e += nt) {
+            const int r = c0 + SB + e / (SB / 2), c = c0 + 2 * (e % (SB / 2));
+            *(d2*)(Mblk + (long long)r * ld + c) = *(const d2*)&Ls[r][c];
+        }
+        for (int e = t; e < (c0 + SB) * (SB / 2); e += nt) {       // LinvT[i][c0+c] = U[i][c0+c], c0+c >= i
+            const int i = e / (SB / 2), c = c0 + 2 * (e % (SB / 2));
+            if (c + 1 >= i) {
+                d2 w;
+                w[0] = (c == i) ? dinv[i] : ((c > i) ? Ls[i][c] : 0.0);
+                w[1] = (c + 1 == i) ? dinv[i] : Ls[i][c + 1];
+                *(d2*)(LinvT + (long long)i * ldinv + c) = w;
             }
         }
-        if (jb == 0) STAMP(11);
-        __syncthreads();
-        if (jb == 0) STAMP(1);
-        if (npanel > 0) {
-            // ---- rank-16 update of the trailing lower triangle, 16x16 MFMA tiles round-robin over waves
-            const int nb16 = npanel / SB;
-            const int ntile = nb16 * (nb16 + 1) / 2;
-            const int base = c0 + SB;
-            for (int t = wave; t < ntile; t += DT / 64) {
-                int bi = 0;
-                while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-                const int bk = t - bi * (bi + 1) / 2;
-                const int i0 = base + SB * bi, k0 = base + SB * bk;
-                d4 cacc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cacc[r] = Ls[i0 + fq + 4 * r][k0 + fr];
-                cacc = mfma_nt16(cacc, Ls, i0, c0, k0, c0, 4, -1.0, fr, fq);
-                store_tile16(Ls, i0, k0, cacc, 1.0, fr, fq);
+        for (int e = t; e < SB * ((c0 + SB) / 2); e += nt) {       // Linv[r][i] = U[i][r], i <= r
+            const int r = c0 + e / ((c0 + SB) / 2), i = 2 * (e % ((c0 + SB) / 2));
+            if (i <= r) {
+                d2 v;
+                v[0] = (i == r) ? dinv[r] : Ls[i][r];
+                v[1] = (i + 1 == r) ? dinv[r] : ((i + 1 < r) ? Ls[i + 1][r] : 0.0);
+                *(d2*)(Linv + (long long)r * ldinv + i) = v;
             }
-            __syncthreads();
-            if (jb == 0) STAMP(2);
         }
+    };
+    for (int jb = 0; jb < NSB - 1; ++jb) {
+        update_tiles(Ls, xid[jb & 1], jb, true, wave, NW, fr, fq);          // the next block column first
+        lds_barrier();
+        if (jb == 0) STAMP(2);
+        if (wave < 3) {
+            __builtin_amdgcn_s_setprio(3);       // the serial chain outranks the throughput work sharing its SIMDs
+            eliminate_block_column(Ls, xid[(jb + 1) & 1], scr[wave], dinv, jb + 1, wave, lane, info, global_row0, Mblk, ld);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            update_tiles(Ls, xid[jb & 1], jb, false, wave - 3, NW - 3, fr, fq);
+            store_block_column(jb, tid - 192, DT - 192);
+        }
+        lds_barrier();
+        if (jb == 0) STAMP(3);
     }
-    STAMP(3);
-    STAMP(4);
-    // ---- write L (lower triangle incl. diagonal) back; the strict upper triangle of M is untouched
-    for (int e = tid * 2; e < NB * NB; e += 2 * DT) {
-        const int r = e >> 7, c = e & 127;
-        if (c + 1 <= r) *(d2*)(Mblk + (long long)r * ld + c) = *(const d2*)&Ls[r][c];
-        else if (c <= r) Mblk[(long long)r * ld + c] = Ls[r][c];
-    }
-    STAMP(5);
-    // ---- inverse of the eight 16x16 diagonal factors, one wave each (lanes 0-15 = rows of the
-    // inverse): x.L16 = e_row solved right to left; L values are wave-uniform broadcast reads.
-    {
-        const int c0 = wave * SB, row = lane & 15;
-        if (lane < SB) scr[wave][0][lane] = rcp_nr(Ls[c0 + lane][c0 + lane]);
-        __builtin_amdgcn_wave_barrier();
-        double x[SB];
-#pragma unroll
-        for (int j = SB - 1; j >= 0; --j) {
-            double s = (row == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = j + 1; k < SB; ++k) s = fma(-x[k], Ls[c0 + k][c0 + j], s);
-            x[j] = s * scr[wave][0][j];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < SB) {
-#pragma unroll
-            for (int c = 0; c < SB; ++c) Ls[c0 + row][c0 + c] = (c <= row) ? x[c] : 0.0;
-        }
-    }
-    __syncthreads();
-    trtri_level<16>(Ls, wave, fr, fq);
-    trtri_level<32>(Ls, wave, fr, fq);
-    trtri_level<64>(Ls, wave, fr, fq);
     STAMP(6);
-    for (int e = tid * 2; e < NB * NB; e += 2 * DT) {
-        const int r = e >> 7, c = e & 127;
-        d2 v = *(const d2*)&Ls[r][c];
-        if (c > r) v[0] = 0.0;
-        if (c + 1 > r) v[1] = 0.0;
-        *(d2*)(Linv + (long long)r * ldinv + c) = v;
-        // transposed copy (upper triangular), same (r, c) walk so the global stores stay coalesced
-        d2 w = (d2){Ls[c][r], Ls[c + 1][r]};
-        if (r > c) w[0] = 0.0;
-        if (r > c + 1) w[1] = 0.0;
-        *(d2*)(LinvT + (long long)r * ldinv + c) = w;
-    }
+    store_block_column(NSB - 1, tid, DT);
     STAMP(7);
 #undef STAMP
 }

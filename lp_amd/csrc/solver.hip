@@ -556,10 +556,9 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
             g_diag_stamps = nullptr;
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
             (void)hipFree(d);
-            fprintf(stderr, "diag stamps (cycles): elim16(jb=0) %lld, update(jb=0) %lld, all 8 blocks %lld, writeL %lld, inverse %lld, writeInv %lld\n",
-                    h[1]-h[0], h[2]-h[1], h[3]-h[0], h[5]-h[4], h[6]-h[5], h[7]-h[6]);
-            fprintf(stderr, "  elim detail: load a %lld, 16 steps %lld, rsqrt scale %lld, write back %lld, barrier %lld\n",
-                    h[8]-h[0], h[9]-h[8], h[10]-h[9], h[11]-h[10], h[1]-h[11]);
+            fprintf(stderr, "diag stamps (cycles): elim(0) %lld, priority update(0) %lld, elim(1)||rest(0) %lld, whole factorisation %lld, write inverses %lld\n",
+                    h[1]-h[0], h[2]-h[1], h[3]-h[2], h[6]-h[0], h[7]-h[6]);
+
         }
     }
     int32_t info = 0;
