@@ -155,3 +155,79 @@ def test_repeat_solve_is_bitwise_deterministic(ctx):
     r1 = ctx.solve_raw(o)
     r2 = ctx.solve_raw(o)
     assert r1[3] == r2[3] and np.array_equal(r1[1], r2[1])
+
+
+GOLDEN = ["planted_64x128_s0", "planted_100x333_s1", "planted_256x512_s0", "planted_512x1024_s0",
+          "planted_4096x8192_s0"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_against_committed_golden_vectors(ctx, name):
+    """HIP path vs the committed fixtures (tests/golden/*.npz, produced by the oracle; see make_golden.py),
+    including the headline size m=4096 n=8192 (BASELINE config C3): same iteration count,
+    |x_gpu - x_golden|_inf <= 1e-6, step lengths to 1e-6."""
+    import os
+    import lp_amd as lp
+    from lp_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    dims, seed = name.split("_")[1], int(name.split("_s")[1])
+    m, n = (int(v) for v in dims.split("x"))
+    A, b, c, _ = synth.planted_lp(seed, m, n)
+    ctx.upload_arrays(A, b, c)
+    rc, x, fun, it, rows = ctx.solve_raw(lp.InteriorPoint.default().opts(), want_log=True)
+    assert rc == 0 and it == int(g["iterations"])
+    assert np.abs(x - g["x_slack"]).max() <= X_TOL
+    assert abs(fun - float(g["fun"])) <= 1e-6 * max(1.0, abs(float(g["fun"])))
+    assert np.abs(np.array(rows)[:, 0] - g["log"][:, 0]).max() < 1e-6
+
+
+def test_full_size_properties(ctx):
+    """Size-independent checks at m=4096 n=8192 with no oracle in the loop: the solution is primal
+    feasible (|Ax - b| small), sits on the planted vertex, and the duality gap closes."""
+    import lp_amd as lp
+    from lp_amd import synth
+    m, n = 4096, 8192
+    A, b, c, xstar = synth.planted_lp(1, m, n)
+    ctx.upload_arrays(A, b, c)
+    rc, x, fun, it, rows = ctx.solve_raw(lp.InteriorPoint.default().opts(), want_log=True)
+    assert rc == 0 and 4 <= it <= 12
+    assert np.abs(A @ x - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+    assert x.min() > -1e-9
+    assert np.abs(x - xstar).max() < 1e-5
+    assert abs(fun - c @ xstar) <= 1e-6 * abs(c @ xstar)
+    assert rows[-1][1] < 1e-8 and rows[-1][2] < 1e-8 and rows[-1][3] < 1e-8   # rho_p, rho_d, rho_A < tol
+
+
+def test_solve_batch_shard(built):
+    """lpipm_solve_batch (BASELINE config C4 shape at a reduced count): a shard of independent LPs on one
+    device, each checked against the oracle; mixed sizes and one infeasible member."""
+    import ctypes as C
+    import lp_amd as lp
+    from lp_amd import _capi, synth
+    from oracle import capi as oracle
+    probs = [synth.planted_lp(s, 256, 512)[:3] for s in range(3)] + [synth.planted_lp(7, 128, 200)[:3]]
+    probs.append((np.array([[1.0, 1.0]]), np.array([-1.0]), np.array([1.0, 1.0])))    # infeasible
+    k = len(probs)
+    dp = C.POINTER(C.c_double)
+    As = [np.ascontiguousarray(p[0]) for p in probs]
+    bs = [np.ascontiguousarray(p[1]) for p in probs]
+    cs = [np.ascontiguousarray(p[2]) for p in probs]
+    xs = [np.full(a.shape[1], np.nan) for a in As]
+    arr = lambda lst: (dp * k)(*[a.ctypes.data_as(dp) for a in lst])
+    m = (C.c_uint64 * k)(*[a.shape[0] for a in As])
+    n = (C.c_uint64 * k)(*[a.shape[1] for a in As])
+    c0 = (C.c_double * k)(*([0.0] * k))
+    fun = (C.c_double * k)()
+    its = (C.c_uint64 * k)()
+    st = (C.c_int32 * k)()
+    o = lp.InteriorPoint.default().opts()
+    ctx = lp.default_context(0)
+    rc = _capi.lib().lpipm_solve_batch(ctx._h, k, m, n, arr(As), arr(bs), arr(cs), c0, C.byref(o), arr(xs), fun, its, st)
+    assert rc == 0
+    for i in range(k):
+        ref = oracle.solve(As[i], bs[i], cs[i])
+        assert st[i] == ref["status"]
+        if ref["status"] == 0:
+            assert its[i] == ref["iterations"]
+            assert np.abs(xs[i] - ref["x_slack"]).max() <= X_TOL
+    assert st[k - 1] == _capi.INFEASIBLE
