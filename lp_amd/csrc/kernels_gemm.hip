@@ -162,7 +162,13 @@ __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (
     const int srow = tid >> 3;  /* staging: 32 rows per pass, 8 lanes per 128-B row segment */ \
     const int scol = (tid & 7) * 2;
 
-// Stream-K A.D.A^T (also usable unscaled): ntiles*KT k-tile iterations split evenly over the grid.
+// A.D.A^T (also usable unscaled): data-parallel + stream-K hybrid.
+//   phase 1: the first ntiles_dp = floor(ntiles/nwg)*nwg tiles, one whole tile per workgroup per
+//            round.  Every workgroup walks k from 0 in lockstep, so the ~64 workgroups of an XCD
+//            (one 8x8 super-block of tiles) hit each other's A panels in that XCD's L2.
+//   phase 2: the remaining tiles' k-tile iterations are split evenly over all workgroups
+//            (stream-K): the tail that would otherwise leave most CUs idle.  A workgroup's partial
+//            first/last tile goes to a slab; gemm_nt_fixup_kernel adds the slabs in workgroup order.
 template <bool SCALE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) {
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
@@ -170,14 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) 
     TILE_THREAD_IDS
     const int g = xcd_remap(blockIdx.x, gridDim.x);
     const int KT = p.KT;
-    const long long total = (long long)p.ntiles * KT;
-    long long it = wg_begin(g, total, p.nwg);
-    const long long end = wg_begin(g + 1, total, p.nwg);
-    bool first = true;
-    while (it < end) {
-        const int tile = (int)(it / KT);
-        const int kb = (int)(it - (long long)tile * KT);
-        const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
+    const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
+
+    for (int tile = g; tile < ntiles_dp; tile += p.nwg) {
         int ti, tj;
         tile_coords(p, tile, ti, tj);
         d4 acc[4][4];
@@ -186,12 +187,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) 
 #pragma unroll
             for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
         tile_mainloop<SCALE, 4, 4>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                             p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow,
-                             scol, wr, wc, fr, fq);
+                                   p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, 0, KT, acc, srow,
+                                   scol, wr, wc, fr, fq);
+        double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 64 + fr);
+        tile_store<4, 4>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj && wr == wc,
+                         ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
+    }
+
+    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
+    long long it = wg_begin(g, total, p.nwg);
+    const long long end = wg_begin(g + 1, total, p.nwg);
+    bool first = true;
+    while (it < end) {
+        const int rt = (int)(it / KT);                       // remainder-tile index
+        const int kb = (int)(it - (long long)rt * KT);
+        const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
+        int ti, tj;
+        tile_coords(p, ntiles_dp + rt, ti, tj);
+        d4 acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+        tile_mainloop<SCALE, 4, 4>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
+                                   p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow,
+                                   scol, wr, wc, fr, fq);
         if (kb == 0 && ke == KT) {
             double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 64 + fr);
             tile_store<4, 4>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj && wr == wc,
-                       ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
+                             ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
         } else {
             double* sb0 = p.ws + ((long long)(2 * g + (first ? 0 : 1))) * (TILE * TILE) +
                           (wr * 64 + fq) * TILE + wc * 64 + fr;
@@ -247,17 +271,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileD
     tile_store<4, 4>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
 }
 
-// Adds the partial slabs of every tile whose k-range was split, in workgroup order.
+// Adds the partial slabs of every stream-K (remainder) tile whose k-range was split, in workgroup
+// order.  grid = remainder tiles x FIX_SPLIT: a tile can have dozens of slabs, so its 16K elements are
+// spread over FIX_SPLIT workgroups (8 rows each) to keep this pass off the critical path.
+constexpr int FIX_SPLIT = 16;
 __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p) {
-    const int tile = blockIdx.x;
     const int KT = p.KT;
-    const long long total = (long long)p.ntiles * KT;
-    const long long it0 = (long long)tile * KT, it1 = it0 + KT;
+    const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
+    const int rt = blockIdx.x / FIX_SPLIT, chunk = blockIdx.x % FIX_SPLIT;
+    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
+    const long long it0 = (long long)rt * KT, it1 = it0 + KT;
     const int g_lo = wg_owner(it0, total, p.nwg), g_hi = wg_owner(it1 - 1, total, p.nwg);
     if (g_lo == g_hi) return;  // one workgroup computed the whole tile and wrote it directly
     int ti, tj;
-    tile_coords(p, tile, ti, tj);
-    for (int e = threadIdx.x * 2; e < TILE * TILE; e += 512) {
+    tile_coords(p, ntiles_dp + rt, ti, tj);
+    constexpr int PER = TILE * TILE / FIX_SPLIT;
+    for (int e = chunk * PER + threadIdx.x * 2; e < (chunk + 1) * PER; e += 512) {
         d2 sum = (d2){0.0, 0.0};
         for (int g = g_lo; g <= g_hi; ++g) {
             const int slot = wg_begin(g, total, p.nwg) >= it0 ? 0 : 1;
@@ -301,12 +330,13 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, dim3(a.nwg), dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // a split exists unless every workgroup boundary falls on a tile boundary
-    const long long total = (long long)a.ntiles * k.KT;
+    // remainder tiles: a split exists unless every workgroup boundary falls on a tile boundary
+    const int nrem = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
+    const long long total = (long long)nrem * k.KT;
     bool split = false;
     for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
     if (split) {
-        hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(a.ntiles), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(nrem * FIX_SPLIT), dim3(256), 0, st, k);
         e = hipGetLastError();
     }
     return e;
