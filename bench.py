@@ -126,6 +126,12 @@ def main():
         flops_per_launch = float(m) * (m + 1) * n                     # lower triangle of A.D.A^T
         avg_ms = adat_ms / max(adat_launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (counters
+        # cannot be read from inside this process); the committed summary is profiles/r01_adat_pmc.json.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_adat_pmc.json")
+        if (m, n) == (4096, 8192) and os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch")
         out = {
             "metric": "IPM iterations/sec, dense 4096x8192 fp64 LP",
             "value": iters_total / dt_max,
@@ -143,10 +149,14 @@ def main():
                                    f"(seed = rank), reference default options, A resident in HBM",
                        "m": m, "n": n, "iterations_per_solve": iters_local / args.steps,
                        "max_abs_err_vs_planted_optimum": err},
-            "roofline": {"kernel": "gemm_nt_kernel (A.diag(x/z).A^T, lower tiles, fp64 MFMA 16x16x4)",
+            "roofline": {"kernel": "gemm_nt_streamk_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
+                                   "v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": avg_ms, "launches": adat_launches,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                                             "profiles/r01_adat_pmc.json)",
+                         "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
+                         "avg_launch_ms": avg_ms, "launches": adat_launches,
                          "flops_per_launch": flops_per_launch},
             "phase_ms_per_iteration": {k: v / max(iters_local, 1) for k, v in phase.items()},
         }

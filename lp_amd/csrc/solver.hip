@@ -204,17 +204,21 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     delete c;
 }
 
-// Order in which the lower-triangular 128x128 tiles of M are handed to workgroups: 8x8 super-blocks
-// (row-major over the lower triangle of super-blocks, row-major inside), so the ~64 workgroups that
-// share an XCD's L2 read 16 row panels of A for 64 tiles.
+// Order in which the lower-triangular 128x128 tiles of M are handed to workgroups.  Workgroups are
+// renumbered so that 64 consecutive tiles run on one XCD (one L2): full off-diagonal 8x8 super-blocks
+// come first, each exactly one such chunk (16 row panels of A feed 64 tiles); the triangular
+// diagonal super-blocks (36 tiles each) follow and are the ones that straddle chunk boundaries.
 static std::vector<int2> adat_tile_order(int nt) {
     std::vector<int2> v;
     v.reserve((size_t)nt * (nt + 1) / 2);
     const int ns = (nt + 7) / 8;
+    auto emit = [&](int SI, int SJ) {
+        for (int ti = SI * 8; ti < nt && ti < SI * 8 + 8; ++ti)
+            for (int tj = SJ * 8; tj < SJ * 8 + 8 && tj <= ti; ++tj) v.push_back(make_int2(ti, tj));
+    };
     for (int SI = 0; SI < ns; ++SI)
-        for (int SJ = 0; SJ <= SI; ++SJ)
-            for (int ti = SI * 8; ti < nt && ti < SI * 8 + 8; ++ti)
-                for (int tj = SJ * 8; tj < SJ * 8 + 8 && tj <= ti; ++tj) v.push_back(make_int2(ti, tj));
+        for (int SJ = 0; SJ < SI; ++SJ) emit(SI, SJ);
+    for (int SI = 0; SI < ns; ++SI) emit(SI, SI);
     return v;
 }
 
