@@ -1,0 +1,58 @@
+//! `extern "C"` surface of include/lpipm.h (only what the shim calls).
+//! The crate denies `unsafe_code` (.cargo/config.toml:6); this module is the one scoped exception.
+#![allow(unsafe_code, non_camel_case_types)]
+
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)]
+pub struct lpipm_ctx {
+    _private: [u8; 0],
+}
+
+/// include/lpipm.h `lpipm_opts` == InteriorPointBuilder fields (interior_point/mod.rs:41-48)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct lpipm_opts {
+    pub tol: f64,
+    pub alpha0: f64,
+    pub max_iter: u64,
+    pub ip: i32,
+    pub solver_type: i32,
+    pub disp: i32,
+}
+
+/// include/lpipm.h `lpipm_iter_row` (indicators.rs:8-23 + alpha)
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lpipm_iter_row {
+    pub alpha: f64,
+    pub rho_p: f64,
+    pub rho_d: f64,
+    pub rho_a: f64,
+    pub rho_g: f64,
+    pub rho_mu: f64,
+    pub obj: f64,
+}
+
+pub const LPIPM_OK: c_int = 0;
+pub const LPIPM_UNCONSTRAINED: c_int = 1;
+pub const LPIPM_NUMERICAL_PROBLEM: c_int = 2;
+pub const LPIPM_INVALID_PARAMETER: c_int = 3;
+pub const LPIPM_INCOMPATIBLE_DIMENSIONS: c_int = 4;
+pub const LPIPM_INFEASIBLE: c_int = 5;
+pub const LPIPM_UNBOUNDED: c_int = 6;
+pub const LPIPM_ITERATION_LIMIT: c_int = 7;
+
+extern "C" {
+    pub fn lpipm_create(device: c_int, out: *mut *mut lpipm_ctx) -> c_int;
+    pub fn lpipm_destroy(ctx: *mut lpipm_ctx);
+    pub fn lpipm_upload(
+        ctx: *mut lpipm_ctx, m: u64, n: u64, a: *const f64, lda: u64, b: *const f64, c: *const f64, c0: f64,
+    ) -> c_int;
+    pub fn lpipm_solve(
+        ctx: *mut lpipm_ctx, opts: *const lpipm_opts, x_slack_out: *mut f64, fun_out: *mut f64,
+        iterations_out: *mut u64, log: *mut lpipm_iter_row,
+    ) -> c_int;
+    pub fn lpipm_strerror(status: c_int) -> *const c_char;
+    pub fn lpipm_last_error_detail() -> *const c_char;
+}

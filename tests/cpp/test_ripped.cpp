@@ -1,0 +1,114 @@
+// test_ripped.cpp -- the reference's own known-answer tests (src/lib.rs:77-114,
+// src/solvers/interior_point/mod.rs:243-345) restated against include/ripped.hpp.
+//   ./test_ripped host   : host-side logic only (no GPU): builders, validation, error mapping
+//   ./test_ripped gpu    : everything, through liblpipm.so on device 0
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ripped.hpp"
+
+using namespace ripped;
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+static bool close(const std::vector<double>& a, const std::vector<double>& b, double eps) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); ++i)
+        if (!(std::fabs(a[i] - b[i]) <= eps)) return false;
+    return true;
+}
+
+static Matrix mat(std::vector<double> d, uint64_t r, uint64_t c) { return Matrix{std::move(d), r, c}; }
+
+static Problem make_problem() {  // src/lib.rs:84-96
+    static const Matrix A_ub = mat({-3, 1, 1, 2}, 2, 2), A_eq = mat({1, 1}, 1, 2);
+    static const std::vector<double> b_ub{6, 4}, b_eq{1}, c{-1, 4};
+    return Problem::target(c).ub(A_ub, b_ub).eq(A_eq, b_eq).build();
+}
+
+static void host_tests() {
+    // test_problem_interface, src/lib.rs:97-104 (+ slack form of linear_program.rs:145-160)
+    Problem p = make_problem();
+    CHECK(p.A().rows == 3 && p.A().cols == 4 && p.n_slack() == 2 && p.c0() == 0.0);
+    CHECK(close(p.A().data, {-3, 1, 1, 0, 1, 2, 0, 1, 1, 1, 0, 0}, 0.0));
+    CHECK(close(p.b(), {6, 4, 1}, 0.0) && close(p.c(), {-1, 4, 0, 0}, 0.0));
+    // default_builder_doesnt_panic, mod.rs:249-254
+    CHECK(InteriorPoint::default_() == InteriorPoint::custom().build());
+    // InteriorPointBuilder::build validation, mod.rs:118-128
+    for (double bad : {0.0, 1.0, -0.5, 2.0}) {
+        try { InteriorPoint::custom().alpha0(bad).build(); CHECK(false); }
+        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::InvalidParameter); }
+    }
+    try { InteriorPoint::custom().tol(0.0).build(); CHECK(false); }
+    catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::InvalidParameter); }
+    // linear_program.rs:134-143
+    std::vector<double> c{1, 2};
+    try { Problem::target(c).build(); CHECK(false); }
+    catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Unconstrained); }
+    Matrix bad = mat({1}, 1, 1);
+    std::vector<double> bb{1};
+    try { Problem::target(c).ub(bad, bb).build(); CHECK(false); }
+    catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::IncompatibleInputDimensions); }
+}
+
+static void gpu_tests() {
+    // test_interior_point_interface (src/lib.rs:106-113), test_interior_point_builder (mod.rs:256-273)
+    {
+        OptimizeResult res = InteriorPoint::default_().solve(make_problem());
+        CHECK(close(res.x(), {1, 0}, 1e-6));
+        CHECK(res.iteration() == 4 && std::fabs(res.fun() + 1.0) < 1e-6);
+    }
+    {   // crate doctest, src/lib.rs:39-51
+        InteriorPoint s = InteriorPoint::custom().solver_type(EquationSolverType::Cholesky).tol(1e-8).disp(false)
+                              .ip(true).alpha0(0.99995).max_iter(1000).build();
+        CHECK(close(s.solve(make_problem()).x(), {1, 0}, 1e-6));
+    }
+    {   // InteriorPoint::custom doctest, mod.rs:175-194
+        Matrix A_ub = mat({-3, 1, 1, 2}, 2, 2);
+        std::vector<double> b_ub{6, 4}, c{-1, 4};
+        CHECK(close(InteriorPoint::custom().build().solve(Problem::target(c).ub(A_ub, b_ub).build()).x(), {4, 0}, 1e-6));
+    }
+    Matrix A3 = mat({2, 1, 0, 0, 2, 1, 1, 0, 2}, 3, 3);
+    std::vector<double> b3{1, 2, 3}, c3{-1, 4, -1.2};
+    {   // test_linprog_eq_only, mod.rs:319-331
+        CHECK(close(InteriorPoint::default_().solve(Problem::target(c3).eq(A3, b3).build()).x(),
+                    {1.0 / 3, 1.0 / 3, 4.0 / 3}, 1e-6));
+    }
+    {   // test_linprog_ub_only, mod.rs:332-344
+        CHECK(close(InteriorPoint::default_().solve(Problem::target(c3).ub(A3, b3).build()).x(), {0.5, 0.0, 1.25}, 1e-6));
+    }
+    {   // Inverse / LeastSquares arms (mod.rs:275-317) are not built yet: the backend must say so, loudly
+        try { InteriorPoint::custom().solver_type(EquationSolverType::Inverse).build().solve(make_problem()); CHECK(false); }
+        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Backend); }
+    }
+    {   // exits the reference defines but never tests: indicators.rs:66-83, mod.rs:232-239
+        Matrix Ae = mat({1, 1}, 1, 2);
+        std::vector<double> be{-1}, ce{1, 1};
+        try { InteriorPoint::default_().solve(Problem::target(ce).eq(Ae, be).build()); CHECK(false); }
+        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Infeasible); }
+        Matrix Au = mat({1, -1}, 1, 2);
+        std::vector<double> bu{0}, cu{-1, 0};
+        try { InteriorPoint::default_().solve(Problem::target(cu).eq(Au, bu).build()); CHECK(false); }
+        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Unbounded); }
+        try { InteriorPoint::custom().max_iter(2).build().solve(make_problem()); CHECK(false); }
+        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::IterationLimitExceeded && e.best_x().size() == 4); }
+    }
+    {   // examples/symmetric.rs:10-25
+        const uint64_t N = 1000;
+        Matrix A; A.rows = A.cols = N; A.data.assign(N * N, 1.0);
+        for (uint64_t i = 0; i < N; ++i) A.data[i * N + i] = 0.0;
+        std::vector<double> b(N, (double)(N - 1)), c(N, -1.0);
+        OptimizeResult r = InteriorPoint::custom().build().solve(Problem::target(c).ub(A, b).build());
+        CHECK(close(r.x(), std::vector<double>(N, 1.0), 1e-10) && r.iteration() == 4);
+    }
+}
+
+int main(int argc, char** argv) {
+    host_tests();
+    if (argc > 1 && !std::strcmp(argv[1], "gpu")) gpu_tests();
+    std::printf(failures ? "%d FAILED\n" : "all ok\n", failures);
+    return failures ? 1 : 0;
+}
