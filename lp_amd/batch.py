@@ -1,0 +1,84 @@
+"""Batches of independent LPs sharded one-shard-per-GPU (BASELINE config C4 / SURVEY.md 8e).
+
+LPs are independent, so the path shards with NO data-path collective: rank r solves the contiguous
+block `shard_range(count, world, r)` on its own GPU (its own lpipm_ctx / stream), and the batch ends
+with exactly ONE collective -- an all-gather (RCCL over xGMI when the backend is "nccl") of a packed
+[shard_max, n_max + 3] block per rank holding x / tau, fun, iterations and status of each LP.
+One process per GPU, `torch.distributed` for the plumbing; nothing here computes on the CPU.
+`solve_fn` exists so that the sharding / packing / gather logic can be unit-tested on CPU ranks
+(gloo) with an injected solver; the default is the HIP path and it fails loudly without a GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+
+
+def shard_range(count: int, world: int, rank: int) -> range:
+    """Static block partition: the first `count % world` ranks get one extra LP."""
+    base, extra = divmod(count, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def _hip_solve_fn(ctx, opts):
+    def solve(A, b, c, c0, x_out_row):
+        ctx.upload_arrays(A, b, c, c0)
+        # x / tau goes straight into the packed device row (no host round trip for the solution)
+        rc, _, fun, it, _ = ctx.solve_raw(opts, x_dev_ptr=x_out_row.data_ptr())
+        return rc, None, fun, it
+    return solve
+
+
+def solve_batch_sharded(problems, opts=None, ctx=None, group=None, device=None, solve_fn=None):
+    """problems: sequence of (A, b, c, c0) -- every rank passes the same list (or at least its shard
+    at the right indices).  Returns, on EVERY rank, a list of dicts {status, x_slack, fun, iterations}
+    in problem order.  `solve_fn(A, b, c, c0, x_out_row) -> (status, x | None, fun, iterations)` may
+    write x into x_out_row itself (device path) or return it (test path)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    count = len(problems)
+    mine = shard_range(count, world, rank)
+    shard_max = -(-count // world) if count else 0
+    n_max = max((np.asarray(p[2]).shape[0] for p in problems), default=0)
+    if solve_fn is None:
+        import lp_amd
+        ctx = ctx or lp_amd.default_context(device.index if device is not None and device.index is not None else 0)
+        opts = opts or lp_amd.InteriorPoint.default().opts()
+        solve_fn = _hip_solve_fn(ctx, opts)
+        device = device or torch.device("cuda", ctx.device)
+    device = device or torch.device("cpu")
+    packed = torch.zeros((max(shard_max, 1), n_max + 3), dtype=torch.float64, device=device)
+    packed[:, n_max + 2] = -1.0                       # status -1: padding slot, no LP here
+    for slot, i in enumerate(mine):
+        A, b, c, c0 = problems[i]
+        n = np.asarray(c).shape[0]
+        rc, x, fun, it = solve_fn(A, b, c, c0, packed[slot])
+        if x is not None:
+            packed[slot, :n] = torch.as_tensor(np.asarray(x, dtype=np.float64)).to(device)
+        ok = rc in (_capi.OK, _capi.ITERATION_LIMIT)
+        tail = torch.tensor([fun if ok and fun is not None else float("nan"), float(it), float(rc)],
+                            dtype=torch.float64)
+        packed[slot, n_max:] = tail.to(device)
+    if world > 1:
+        flat = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(flat, packed, group=group)         # the single collective of the batch
+        gathered = flat.view(world, packed.shape[0], packed.shape[1])
+    else:
+        gathered = packed.unsqueeze(0)
+    g = gathered.cpu().numpy()
+    out = []
+    for i in range(count):
+        r = next(rr for rr in range(world) if i in shard_range(count, world, rr))
+        slot = i - shard_range(count, world, r).start
+        row = g[r, slot]
+        n = np.asarray(problems[i][2]).shape[0]
+        status = int(row[n_max + 2])
+        has_x = status in (_capi.OK, _capi.ITERATION_LIMIT)
+        out.append(dict(status=status, x_slack=row[:n].copy() if has_x else None,
+                        fun=float(row[n_max]) if has_x else None, iterations=int(row[n_max + 1])))
+    return out

@@ -231,3 +231,23 @@ def test_solve_batch_shard(built):
             assert its[i] == ref["iterations"]
             assert np.abs(xs[i] - ref["x_slack"]).max() <= X_TOL
     assert st[k - 1] == _capi.INFEASIBLE
+
+
+def test_sharded_batch_device_path(built):
+    """lp_amd.batch on the real HIP solver (world = 1: the shard is the whole batch; x / tau is written by
+    the library straight into the packed device rows): C4-shaped members + ragged + infeasible."""
+    import lp_amd as lp
+    from lp_amd import synth
+    from lp_amd.batch import solve_batch_sharded
+    from oracle import capi as oracle
+    probs = [synth.planted_lp(s, 1024, 2048)[:3] + (0.0,) for s in range(2)]
+    probs += [synth.planted_lp(9, 100, 333)[:3] + (0.0,)]
+    probs.append((np.array([[1.0, 1.0]]), np.array([-1.0]), np.array([1.0, 1.0]), 0.0))
+    res = solve_batch_sharded(probs)
+    for (A, b, c, c0), r in zip(probs, res):
+        ref = oracle.solve(A, b, c, c0)
+        assert r["status"] == ref["status"]
+        if ref["status"] == 0:
+            assert r["iterations"] == ref["iterations"]
+            assert np.abs(r["x_slack"] - ref["x_slack"]).max() <= X_TOL
+            assert abs(r["fun"] - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
