@@ -67,6 +67,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C lp_amd/csrc`).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  If liblpipm.so pulled the system one in first, a later `import torch` would
+        # be bound to it and fail to see the GPU ("No HIP GPUs are available").  Loading torch first
+        # makes both sides share torch's runtime (device pointers of torch tensors stay valid here).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the header and the library ever diverge
