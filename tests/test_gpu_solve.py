@@ -251,3 +251,25 @@ def test_sharded_batch_device_path(built):
             assert r["iterations"] == ref["iterations"]
             assert np.abs(r["x_slack"] - ref["x_slack"]).max() <= X_TOL
             assert abs(r["fun"] - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
+
+
+@pytest.mark.parametrize("kw", [dict(ip=False), dict(tol=1e-6), dict(alpha0=0.9), dict(ip=False, tol=1e-10, alpha0=0.999),
+                                dict(max_iter=3)])
+def test_non_default_options_match_oracle(ctx, kw):
+    """InteriorPointBuilder options (interior_point/mod.rs:62-114) change the trajectory; the HIP path must
+    follow the oracle through every variant (ip=false start: feasible_point.rs:119-120, rhat.rs:62-66)."""
+    import lp_amd as lp
+    from lp_amd import synth, _capi
+    from oracle import capi as oracle
+    A, b, c, _ = synth.planted_lp(2, 200, 420)
+    ctx.upload_arrays(A, b, c)
+    bld = lp.InteriorPoint.custom()
+    for k, v in kw.items():
+        bld = getattr(bld, k)(v)
+    rc, x, fun, it, rows = ctx.solve_raw(bld.build().opts(), want_log=True)
+    ref = oracle.solve(A, b, c, 0.0, oracle.default_opts(**{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}))
+    assert rc == ref["status"] and it == ref["iterations"]
+    assert rc in (_capi.OK, _capi.ITERATION_LIMIT)
+    assert np.abs(x - ref["x_slack"]).max() <= X_TOL * max(1.0, np.abs(ref["x_slack"]).max())
+    got, exp = np.array(rows), np.array(ref["log"])
+    assert np.abs(got[:, 0] - exp[:, 0]).max() < 1e-6
