@@ -85,24 +85,22 @@ __device__ __forceinline__ void tile_mainloop(double (*ldsA)[32 * MTM][LDS_STRID
                                               const double* __restrict__ Qp, long long ldq,
                                               const double* __restrict__ s, int kb, int ke, d4 (&acc)[MTM][MTN],
                                               int srow, int scol, int wr, int wc, int fr, int fq) {
-    d2 sa[MTM], sb[MTN];
+    d2 sa[MTM], sb[MTN], sv = (d2){1.0, 1.0};
     auto gload = [&](int kt) {
         const long long ko = (long long)kt * BK;
 #pragma unroll
         for (int r = 0; r < MTM; ++r) sa[r] = *(const d2*)(Pp + (long long)(32 * r) * ldp + ko);
 #pragma unroll
         for (int r = 0; r < MTN; ++r) sb[r] = *(const d2*)(Qp + (long long)(32 * r) * ldq + ko);
-        if (SCALE) {
-            const d2 sv = *(const d2*)(s + ko + scol);
-#pragma unroll
-            for (int r = 0; r < MTN; ++r) sb[r] = sb[r] * sv;
-        }
+        if (SCALE) sv = *(const d2*)(s + ko + scol);
     };
+    // the scale is applied here, after the MFMAs of the current k-tile: multiplying right after the
+    // loads would make the wave wait for the prefetch it has just issued
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int r = 0; r < MTM; ++r) *(d2*)&ldsA[buf][srow + 32 * r][scol] = sa[r];
 #pragma unroll
-        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = sb[r];
+        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = SCALE ? sb[r] * sv : sb[r];
     };
     gload(kb);
     lstore(0);
@@ -140,6 +138,22 @@ __device__ __forceinline__ void tile_mainloop(double (*ldsA)[32 * MTM][LDS_STRID
 template <int MTM, int MTN>
 __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (&acc)[MTM][MTN], double alpha,
                                            double beta, bool pad_diag, int row0, int diag_pad_from, int fr, int fq) {
+    if (beta != 0.0) {   // wave-uniform.  All C values of a 16-row block are requested before any is used.
+#pragma unroll
+        for (int mi = 0; mi < MTM; ++mi) {
+            double cv[4][MTN];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nj = 0; nj < MTN; ++nj) cv[r][nj] = cb[(long long)(mi * 16 + 4 * r) * ldc + nj * 16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nj = 0; nj < MTN; ++nj)
+                    cb[(long long)(mi * 16 + 4 * r) * ldc + nj * 16] = fma(alpha, acc[mi][nj][r], beta * cv[r][nj]);
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MTM; ++mi)
 #pragma unroll
@@ -148,7 +162,6 @@ __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (
 #pragma unroll
             for (int nj = 0; nj < MTN; ++nj) {
                 double v = alpha * acc[mi][nj][r];
-                if (beta != 0.0) v += beta * rp[nj * 16];
                 if (pad_diag && mi == nj && fq + 4 * r == fr && row0 + mi * 16 + 4 * r >= diag_pad_from) v = 1.0;
                 rp[nj * 16] = v;
             }
@@ -253,6 +266,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(const GemmK p) {
     tile_store<MTM, MTN>(cb, p.ldc, acc, p.alpha, p.beta, false, 0, -1, fr, fq);
 }
 
+// K = 128 specialisation of the whole-tile kernel for the latency-bound steps of the factorisation
+// (panel solve, update inside an outer panel): with 16 MFMAs per wave and k-tile the one-ahead
+// prefetch of tile_mainloop cannot hide a global-load round trip, so all 8 k-tiles are requested up
+// front (they fit in registers for these small tiles) and the round trip is paid once per tile.
+template <int MTM, int MTN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_k128_kernel(const GemmK p) {
+    constexpr int TM = 32 * MTM, TN = 32 * MTN, KT8 = 8;
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TM][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TN][LDS_STRIDE];
+    TILE_THREAD_IDS
+    int ti, tj;
+    tile_coords(p, blockIdx.x, ti, tj);
+    const double* Pp = p.P + (long long)(ti * TM + srow) * p.ldp + scol;
+    const double* Qp = p.Q + (long long)(tj * TN + srow) * p.ldq + scol;
+    d2 pa[KT8][MTM], pb[KT8][MTN];
+#pragma unroll
+    for (int kt = 0; kt < KT8; ++kt) {
+#pragma unroll
+        for (int r = 0; r < MTM; ++r) pa[kt][r] = *(const d2*)(Pp + (long long)(32 * r) * p.ldp + kt * BK);
+#pragma unroll
+        for (int r = 0; r < MTN; ++r) pb[kt][r] = *(const d2*)(Qp + (long long)(32 * r) * p.ldq + kt * BK);
+    }
+    d4 acc[MTM][MTN];
+#pragma unroll
+    for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < MTN; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < KT8; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int r = 0; r < MTM; ++r) *(d2*)&ldsA[buf][srow + 32 * r][scol] = pa[kt][r];
+#pragma unroll
+        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = pb[kt][r];
+        __syncthreads();   // buffer `buf` was last read two k-tiles ago: that read finished before the previous barrier
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            d2 a[MTM], b[MTN];
+#pragma unroll
+            for (int mi = 0; mi < MTM; ++mi)
+                a[mi] = *(const d2*)&ldsA[buf][wr * (16 * MTM) + mi * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int nj = 0; nj < MTN; ++nj)
+                b[nj] = *(const d2*)&ldsB[buf][wc * (16 * MTN) + nj * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < MTN; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+        }
+    }
+    double* cb = p.C + (long long)(ti * TM + wr * (16 * MTM) + fq) * p.ldc + (tj * TN + wc * (16 * MTN) + fr);
+    tile_store<MTM, MTN>(cb, p.ldc, acc, p.alpha, p.beta, false, 0, -1, fr, fq);
+}
+
 // Grouped GEMM: every workgroup takes its own descriptor (operands, k-range, alpha): the doubling
 // levels of the super-block triangular inverse are a few such launches over many small products.
 __global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileDesc* __restrict__ descs) {
@@ -321,7 +391,9 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
     if (a.nwg == a.ntiles && !a.s && a.diag_pad_from < 0) {   // one whole tile per workgroup
-        if (a.tile_edge == 64)      hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
+        if (a.tile_edge == 64 && k.KT == 8)      hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
+        else if (a.tile_edge == 32 && k.KT == 8) hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<1, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
+        else if (a.tile_edge == 64) hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
         else if (a.tile_edge == 32) hipLaunchKernelGGL((gemm_nt_tile_kernel<1, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
         else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
         return hipGetLastError();
