@@ -128,6 +128,10 @@ int lpipm_solve_batch(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const u
                       const double* c0, const lpipm_opts* opts, double* const* x_slack_out,
                       double* fun_out, uint64_t* iterations_out, int32_t* status_out);
 
+/* Number of LPs of a batch in flight at once on the device (0 = auto, the default: 8 for members up
+ * to m = 2048, else 2; 1 = strictly one after the other).  Members of a batch are independent, each in-flight member has its own stream and buffers. */
+int lpipm_set_batch_concurrency(lpipm_ctx* ctx, int nworkers);
+
 /* Profiling switch (off by default) and the per-phase device times of the last solve. */
 int lpipm_set_profiling(lpipm_ctx* ctx, int on);
 int lpipm_get_phase_times(const lpipm_ctx* ctx, lpipm_phase_times* out);

