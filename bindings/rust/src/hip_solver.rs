@@ -63,8 +63,11 @@ impl Solver<f64> for InteriorPoint<f64> {
             return Err(to_error(rc, None));
         }
         let ctx = Ctx(raw);
+        // n_slack: the last columns are the [I; 0] slack block (linear_program.rs:147-161); the backend
+        // then neither copies nor multiplies them
         let rc = unsafe {
-            lpipm_upload(ctx.0, m as u64, n as u64, a.as_ptr(), n as u64, b.as_ptr(), c.as_ptr(), problem.c0())
+            lpipm_upload_slack(ctx.0, m as u64, n as u64, a.as_ptr(), n as u64, b.as_ptr(), c.as_ptr(),
+                               problem.c0(), problem.n_slack() as u64)
         };
         if rc != LPIPM_OK {
             return Err(to_error(rc, None));

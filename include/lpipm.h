@@ -104,6 +104,14 @@ void lpipm_destroy(lpipm_ctx* ctx);
 int lpipm_upload(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                  const double* b, const double* c, double c0);
 
+/* Same upload with the structural hint `Problem` carries (n_slack, linear_program.rs:161): the last
+ * n_slack columns of A are the slack block [I; 0] of `ub` constraints (linear_program.rs:147-156).
+ * They are then neither copied to the device nor multiplied: M = A_x D_x A_x^T + diag(D_s), A.w adds
+ * w_s, A^T.v copies v.  The hint is verified; a matrix without that structure is treated as dense.
+ * Results agree with lpipm_upload to rounding (same iteration counts on every test). */
+int lpipm_upload_slack(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A, uint64_t lda,
+                       const double* b, const double* c, double c0, uint64_t n_slack);
+
 /* InteriorPoint::solve_normal_form + the `fun` of solve (mod.rs:199-240, :165).
  *   x_slack_out[n] : x / tau  (mod.rs:231); ALSO filled for LPIPM_ITERATION_LIMIT (mod.rs:237-239)
  *   fun_out        : c . x_slack + c0  (linear_program.rs:61-63)

@@ -177,8 +177,9 @@ public:
         raise_for(lpipm_create(device_, &ctx));
         struct Guard { lpipm_ctx* c; ~Guard() { lpipm_destroy(c); } } guard{ctx};
         const Matrix& A = problem.A();
-        raise_for(lpipm_upload(ctx, A.rows, A.cols, A.data.data(), A.cols, problem.b().data(), problem.c().data(),
-                               problem.c0()));
+        // n_slack tells the backend that the last columns are the [I; 0] slack block (linear_program.rs:147-161)
+        raise_for(lpipm_upload_slack(ctx, A.rows, A.cols, A.data.data(), A.cols, problem.b().data(),
+                                     problem.c().data(), problem.c0(), problem.n_slack()));
         std::vector<double> x(A.cols);
         double fun = 0.0;
         uint64_t it = 0;

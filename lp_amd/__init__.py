@@ -233,16 +233,16 @@ class Context:
         except Exception:
             pass
 
-    def upload(self, problem: Problem):
+    def upload(self, problem: Problem, use_slack_structure: bool = True):
         A, b, c = _f64(problem.A()), _f64(problem.b()), _f64(problem.c())
-        return self.upload_arrays(A, b, c, problem.c0())
+        return self.upload_arrays(A, b, c, problem.c0(), problem.n_slack() if use_slack_structure else 0)
 
-    def upload_arrays(self, A, b, c, c0=0.0):
+    def upload_arrays(self, A, b, c, c0=0.0, n_slack=0):
         A, b, c = _f64(A), _f64(b), _f64(c)
         if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
             raise IncompatibleInputDimensions()
         m, n = A.shape
-        rc = _capi.lib().lpipm_upload(self._h, m, n, _p(A), n, _p(b), _p(c), float(c0))
+        rc = _capi.lib().lpipm_upload_slack(self._h, m, n, _p(A), n, _p(b), _p(c), float(c0), int(n_slack))
         _raise_for(rc)
         self.m, self.n = m, n
         return self

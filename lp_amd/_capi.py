@@ -41,6 +41,7 @@ SYMBOLS = {
     "lpipm_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lpipm_destroy": (None, [_vp]),
     "lpipm_upload": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
+    "lpipm_upload_slack": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double, _u64]),
     "lpipm_solve": (C.c_int, [_vp, C.POINTER(Opts), _dp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_device": (C.c_int, [_vp, C.POINTER(Opts), _vp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_batch": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
 template <int NRHS>
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, long long lda, int np,
                                                      const double* __restrict__ V, long long ldv,
-                                                     double* __restrict__ Upart) {
+                                                     double* __restrict__ Upart, long long slab) {
     __shared__ double vs[NRHS][GEMVT_ROWS];
     const int tid = threadIdx.x;
     const int col = (blockIdx.x * 256 + tid) * 2;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ 
     }
 #pragma unroll
     for (int q = 0; q < NRHS; ++q)
-        *(d2*)(Upart + ((long long)blockIdx.y * NRHS + q) * np + col) = acc[q];
+        *(d2*)(Upart + ((long long)blockIdx.y * NRHS + q) * slab + col) = acc[q];
 }
 
 __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __restrict__ Upart, int nsplit,
@@ -122,12 +122,56 @@ hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, 
 }
 
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
-                         int64_t ldv, double* Upart, hipStream_t st) {
+                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab) {
+    if (slab <= 0) slab = np;
     dim3 grid((np / 2 + 255) / 256, mp / GEMVT_ROWS);
     if (nrhs == 1)
-        hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart);
+        hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab);
     else
-        hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart);
+        hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab);
+    return hipGetLastError();
+}
+
+// ---- slack structure (linear_program.rs:145-156): the last ns columns of the slack-form matrix are
+// [I; 0] and are never stored; their contribution to the three matrix operations is added here.
+//   A.w      : y[i]        += w[nx + i]          (i < ns)
+//   A^T.v    : u[nx + i]    = v[i]               (goes to row-split slab 0; the other slabs hold 0 there)
+//   A.D.A^T  : M[i][i]     += d[nx + i]
+__global__ __launch_bounds__(256) void slack_n_kernel(int ns, int nx, int nrhs, const double* __restrict__ W,
+                                                      long long ldw, double* __restrict__ Y, long long ldy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    for (int q = 0; q < nrhs; ++q) Y[q * ldy + i] += W[q * ldw + nx + i];
+}
+// grid.y = row splits: split 0 receives v, every other split an explicit 0 (the slab buffer is shared by
+// the 1- and 2-vector layouts, so "never written" is not the same as zero)
+__global__ __launch_bounds__(256) void slack_t_kernel(int ns, int nx, int nrhs, const double* __restrict__ V,
+                                                      long long ldv, double* __restrict__ Upart, long long slab) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int sp = blockIdx.y;
+    for (int q = 0; q < nrhs; ++q)
+        Upart[((long long)sp * nrhs + q) * slab + nx + i] = sp == 0 ? V[q * ldv + i] : 0.0;
+}
+__global__ __launch_bounds__(256) void slack_diag_kernel(int ns, int nx, const double* __restrict__ d,
+                                                         double* __restrict__ M, long long ldm) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    M[(long long)i * ldm + i] += d[nx + i];
+}
+hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st) {
+    if (ns <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slack_n_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, nx, nrhs, W, (long long)ldw, Y, (long long)ldy);
+    return hipGetLastError();
+}
+hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab, hipStream_t st) {
+    if (ns <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slack_t_kernel, dim3((ns + 255) / 256, nsplit), dim3(256), 0, st, ns, nx, nrhs, V, (long long)ldv, Upart, (long long)slab);
+    return hipGetLastError();
+}
+hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st) {
+    if (ns <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slack_diag_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, nx, d, M, (long long)ldm);
     return hipGetLastError();
 }
 

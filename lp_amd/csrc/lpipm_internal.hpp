@@ -109,8 +109,13 @@ hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, 
                          hipStream_t st, double alpha = 1.0);
 // Upart[s][r][k] = sum_{i in row split s} A[i][k] * V[r][i];  consumers sum the splits in order.
 constexpr int GEMVT_ROWS = 128;
+// np: columns processed (multiple of 2); slab: stride between slabs (0 = np)
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
-                         int64_t ldv, double* Upart, hipStream_t st);
+                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab = 0);
+// slack structure [I; 0] of the last ns columns (never stored), see kernels_gemv.hip
+hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st);
+hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab, hipStream_t st);
+hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st);
 // U[r][k] = sum_s Upart[s][r][k]   (stand-alone reduce; the solver fuses this into its consumers)
 hipError_t launch_gemv_t_reduce(const double* Upart, int nsplit, int nrhs, int np, double* U,
                                 int64_t ldu, hipStream_t st);

@@ -43,6 +43,7 @@ struct lpipm_ctx {
     bool has_problem = false;
     uint64_t m = 0, n = 0;
     int mp = 0, np = 0, nblk = 1, nsplit = 1;
+    int ns = 0, nx = 0, npa = 0;   // slack columns (not stored), structural columns, their padded count = lda of A
     double c0 = 0.0;
     std::vector<void*> allocs;   // problem-sized device buffers
     std::vector<size_t> alloc_bytes;
@@ -231,18 +232,32 @@ static std::vector<int2> adat_tile_order(int nt) {
 
 extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                             const double* b, const double* cc, double c0) {
+    return lpipm_upload_slack(c, m, n, A, lda, b, cc, c0, 0);
+}
+
+extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
+                                  const double* b, const double* cc, double c0, uint64_t n_slack) {
     if (!c || !A || !b || !cc || lda < n) return LPIPM_ERR_BAD_ARGUMENT;
     if (m == 0) return LPIPM_UNCONSTRAINED;  // linear_program.rs:134-136
-    if (n == 0 || m > (1u << 20) || n > (1u << 24)) return LPIPM_ERR_BAD_ARGUMENT;
+    if (n == 0 || m > (1u << 20) || n > (1u << 24) || n_slack > n || n_slack > m) return LPIPM_ERR_BAD_ARGUMENT;
+    // The hint is only used if the last n_slack columns really are [I; 0] (ProblemBuilder::build
+    // guarantees it, linear_program.rs:147-156); anything else is treated as a dense matrix.
+    if (n_slack == n) n_slack = 0;
+    for (uint64_t i = 0; i < m && n_slack; ++i) {
+        const double* row = A + i * lda + (n - n_slack);
+        for (uint64_t j = 0; j < n_slack; ++j)
+            if (row[j] != ((i == j) ? 1.0 : 0.0)) { n_slack = 0; break; }
+    }
     LP_HIP(hipSetDevice(c->device));
-    const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK);
-    if (!c->has_problem || mp != c->mp || np != c->np) {
+    const uint64_t nx = n - n_slack;
+    const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK), npa = (int)round_up(nx, BK);
+    if (!c->has_problem || mp != c->mp || np != c->np || npa != c->npa) {
         LP_HIP(hipStreamSynchronize(c->st));
         free_list(c->allocs);
         factor_plan_destroy(c->plan);
         c->alloc_bytes.clear();
         c->has_problem = false;
-        c->mp = mp; c->np = np;
+        c->mp = mp; c->np = np; c->npa = npa;
         c->nsplit = mp / GEMVT_ROWS;
         const uint64_t big = m > n ? m : n;
         c->nblk = (int)((big + 255) / 256);
@@ -250,7 +265,7 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
         VecArgs& v = c->va;
         auto& L = c->allocs;
         hipStream_t st = c->st;
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->A, (size_t)mp * np, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->A, (size_t)mp * npa, st));
         double *bb, *ccv;
         LP_TRY(dalloc(L, &c->alloc_bytes, &bb, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &ccv, (size_t)np, st));
         v.b = bb; v.c = ccv;
@@ -273,7 +288,7 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
         c->ntiles = (int)order.size();
-        c->adat_nwg = gemm_streamk_nwg(c->ntiles, np / BK, c->num_cu);
+        c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu);
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->tile_list, order.size(), st));
         LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->ws, (size_t)2 * c->adat_nwg * TILE * TILE, st));
@@ -287,9 +302,10 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
                 LP_HIP(hipMemsetAsync(c->allocs[i], 0, c->alloc_bytes[i], c->st));
     }
     c->m = m; c->n = n; c->c0 = c0;
+    c->ns = (int)n_slack; c->nx = (int)nx;
     c->va.n = (int)n; c->va.m = (int)m;
-    LP_HIP(hipMemcpy2DAsync(c->A, (size_t)np * sizeof(double), A, (size_t)lda * sizeof(double),
-                            (size_t)n * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpy2DAsync(c->A, (size_t)npa * sizeof(double), A, (size_t)lda * sizeof(double),
+                            (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->st));
     LP_HIP(hipMemcpyAsync((void*)c->va.b, b, m * sizeof(double), hipMemcpyHostToDevice, c->st));
     LP_HIP(hipMemcpyAsync((void*)c->va.c, cc, n * sizeof(double), hipMemcpyHostToDevice, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
@@ -298,21 +314,36 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Y = add + A.W and Upart = row-split slabs of A^T.V on the stored structural columns, plus the
+// identity block of the slack columns
+static hipError_t ctx_gemv_n(lpipm_ctx* c, int nrhs, const double* W, const double* add0, const double* add1, double* Y) {
+    hipError_t e = launch_gemv_n(c->A, c->npa, (int)c->m, c->npa, nrhs, W, c->np, add0, add1, Y, c->mp, c->st);
+    if (e != hipSuccess) return e;
+    return launch_slack_n(c->ns, c->nx, nrhs, W, c->np, Y, c->mp, c->st);
+}
+static hipError_t ctx_gemv_t(lpipm_ctx* c, int nrhs, const double* V) {
+    hipError_t e = launch_gemv_t(c->A, c->npa, c->mp, c->npa, nrhs, V, c->mp, c->ATpart, c->st, c->np);
+    if (e != hipSuccess) return e;
+    return launch_slack_t(c->ns, c->nx, nrhs, c->nsplit, V, c->mp, c->ATpart, c->np, c->st);
+}
+
 // M = A . diag(dinv) . A^T, lower tiles (newton_equations.rs:54-57)
 static hipError_t run_adat(lpipm_ctx* c) {
     GemmArgs g{};
-    g.P = c->A; g.ldp = c->np; g.Q = c->A; g.ldq = c->np; g.s = c->va.dinv;
-    g.C = c->M; g.ldc = c->mp; g.K = c->np; g.alpha = 1.0; g.beta = 0.0;
+    g.P = c->A; g.ldp = c->npa; g.Q = c->A; g.ldq = c->npa; g.s = c->va.dinv;
+    g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
     g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg;
-    return launch_gemm_nt(g, c->st);
+    hipError_t e = launch_gemm_nt(g, c->st);
+    if (e != hipSuccess) return e;
+    return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st);   // + diag(D_slack)
 }
 
 static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol) {
     VecArgs& v = c->va;
     // A.x and A^T.y at the current point (residual.rs:23,25)
-    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 1, v.x, c->np, nullptr, nullptr, v.Ax, c->mp, c->st));
-    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 1, v.y, c->mp, c->ATpart, c->st));
+    LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax));
+    LP_HIP(ctx_gemv_t(c, 1, v.y));
     prof_mark(c, T_GEMV);
     vec_residuals(v, is_init, ip_next, tol, c->c0, c->st);
     LP_HIP(hipGetLastError());
@@ -332,22 +363,22 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
-    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 2, v.W, c->np, v.b, v.rP, v.R, c->mp, st));  // :220
+    LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R));  // :220
     prof_mark(c, T_GEMV);
     LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));                     // :221
     prof_mark(c, T_TRSV);
-    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 2, v.R, c->mp, c->ATpart, st));                  // :223
+    LP_HIP(ctx_gemv_t(c, 2, v.R));                  // :223
     prof_mark(c, T_GEMV);
     vec_pq_uv(v, st);                       // :223, delta.rs:29-32,38
     vec_delta(v, 0, ip, 1.0, st);           // delta.rs:33-37, feasible_point.rs:134-136
     vec_corr_setup(v, ip, st);              // rhat.rs:37-75
     prof_mark(c, T_VEC);
     // corrector: only the second sym_solve changes
-    LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, 1, v.W, c->np, v.rP2, nullptr, v.R, c->mp, st));
+    LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R));
     prof_mark(c, T_GEMV);
     LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
     prof_mark(c, T_TRSV);
-    LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, 1, v.R, c->mp, c->ATpart, st));
+    LP_HIP(ctx_gemv_t(c, 1, v.R));
     prof_mark(c, T_GEMV);
     vec_uv_corr(v, st);
     vec_delta(v, 1, ip, o->alpha0, st);     // mod.rs:216-221
@@ -655,7 +686,7 @@ extern "C" int lpipm_k_gemv_n(lpipm_ctx* c, int nrhs, const double* W, double* Y
     LP_HIP(hipMemcpy2DAsync(c->va.W, (size_t)c->np * sizeof(double), W, c->n * sizeof(double), c->n * sizeof(double),
                             nrhs, hipMemcpyHostToDevice, c->st));
     LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
-        LP_HIP(launch_gemv_n(c->A, c->np, (int)c->m, c->np, nrhs, c->va.W, c->np, nullptr, nullptr, c->va.R, c->mp, c->st));
+        LP_HIP(ctx_gemv_n(c, nrhs, c->va.W, nullptr, nullptr, c->va.R));
         return LPIPM_OK;
     }));
     LP_HIP(hipMemcpy2DAsync(Y, c->m * sizeof(double), c->va.R, (size_t)c->mp * sizeof(double), c->m * sizeof(double),
@@ -672,7 +703,7 @@ extern "C" int lpipm_k_gemv_t(lpipm_ctx* c, int nrhs, const double* V, double* U
     LP_HIP(hipMemcpy2DAsync(c->va.R, (size_t)c->mp * sizeof(double), V, c->m * sizeof(double), c->m * sizeof(double),
                             nrhs, hipMemcpyHostToDevice, c->st));
     LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
-        LP_HIP(launch_gemv_t(c->A, c->np, c->mp, c->np, nrhs, c->va.R, c->mp, c->ATpart, c->st));
+        LP_HIP(ctx_gemv_t(c, nrhs, c->va.R));
         LP_HIP(launch_gemv_t_reduce(c->ATpart, c->nsplit, nrhs, c->np, c->va.W, c->np, c->st));
         return LPIPM_OK;
     }));

@@ -273,3 +273,42 @@ def test_non_default_options_match_oracle(ctx, kw):
     assert np.abs(x - ref["x_slack"]).max() <= X_TOL * max(1.0, np.abs(ref["x_slack"]).max())
     got, exp = np.array(rows), np.array(ref["log"])
     assert np.abs(got[:, 0] - exp[:, 0]).max() < 1e-6
+
+
+def test_slack_structure_hint_matches_dense_path(ctx):
+    """with the n_slack hint the identity block [I; 0] of `ub` rows is neither uploaded nor
+    multiplied (lpipm_upload_slack).  Same LP through both uploads: same iterations, x to 1e-9; kernels
+    (A.D.A^T, A.w, A^T.v) against numpy on the full slack-form matrix; a wrong hint falls back to dense."""
+    import lp_amd as lp
+    rng = np.random.default_rng(11)
+    m_ub, m_eq, n = 150, 40, 260
+    A_ub, A_eq = rng.standard_normal((m_ub, n)), rng.standard_normal((m_eq, n))
+    x0 = rng.uniform(0.5, 1.5, n)
+    b_ub, b_eq = A_ub @ x0 + rng.uniform(0.1, 1.0, m_ub), A_eq @ x0
+    c = A_ub.T @ (-rng.uniform(0.1, 1.0, m_ub)) + A_eq.T @ rng.standard_normal(m_eq) + rng.uniform(0.1, 1.0, n)
+    prob = lp.Problem.target(c).ub(A_ub, b_ub).eq(A_eq, b_eq).build()
+    A = prob.A()
+    o = lp.InteriorPoint.default().opts()
+    ctx.upload(prob, use_slack_structure=False)
+    rc0, x_dense, f0, it0, _ = ctx.solve_raw(o)
+    ctx.upload(prob, use_slack_structure=True)
+    rc1, x_slack, f1, it1, _ = ctx.solve_raw(o)
+    assert rc0 == rc1 == 0 and it0 == it1
+    assert np.abs(x_dense - x_slack).max() <= 1e-9 * max(1.0, np.abs(x_dense).max())
+    # kernels on the structured upload vs numpy on the full matrix
+    d = rng.uniform(0.1, 3.0, A.shape[1])
+    M, _ = ctx.k_adat(d)
+    Mref = (A * d) @ A.T
+    il = np.tril_indices(A.shape[0])
+    assert np.abs(M[il] - Mref[il]).max() <= 1e-12 * np.abs(Mref).max()
+    W, V = rng.standard_normal((2, A.shape[1])), rng.standard_normal((2, A.shape[0]))
+    for nrhs in (2, 1, 2):     # alternate layouts: the slab buffer is shared between them
+        Y, _ = ctx.k_gemv_n(W[:nrhs])
+        U, _ = ctx.k_gemv_t(V[:nrhs])
+        assert np.abs(Y - W[:nrhs] @ A.T).max() <= 1e-11 and np.abs(U - V[:nrhs] @ A).max() <= 1e-11
+    # a hint that does not describe the matrix must be ignored, not trusted
+    B = A.copy()
+    B[0, -1] = 0.5
+    ctx.upload_arrays(B, prob.b(), prob.c(), 0.0, prob.n_slack())
+    U2, _ = ctx.k_gemv_t(V[:1])
+    assert np.abs(U2 - V[:1] @ B).max() <= 1e-11
