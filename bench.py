@@ -57,7 +57,7 @@ def main():
     from lp_amd import synth
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LPIPM_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the N>1 path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -73,7 +73,7 @@ def main():
     solver = lp_amd.InteriorPoint.default()              # reference defaults (mod.rs:52-59)
     opts = solver.opts()
     x_dev = torch.zeros(n, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * n, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * n, dtype=torch.float64, device=dev) if dist is not None else None
 
     def barrier():
         if dist is not None:
