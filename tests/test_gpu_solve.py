@@ -312,3 +312,21 @@ def test_slack_structure_hint_matches_dense_path(ctx):
     ctx.upload_arrays(B, prob.b(), prob.c(), 0.0, prob.n_slack())
     U2, _ = ctx.k_gemv_t(V[:1])
     assert np.abs(U2 - V[:1] @ B).max() <= 1e-11
+
+
+def test_c5_shape_on_one_gpu(ctx):
+    """Maximum size of BASELINE.json (config C5: m=16384, n=32768; A 4 GiB, M 2 GiB) on ONE device -- 288 GB of
+    HBM hold it whole.  No oracle at this size (a CPU iteration takes ~20 min): size-independent properties
+    only -- converged indicators, primal feasibility, the planted vertex, objective."""
+    import lp_amd as lp
+    from lp_amd import synth
+    m, n = 16384, 32768
+    A, b, c, xstar = synth.planted_lp(0, m, n)
+    ctx.upload_arrays(A, b, c)
+    rc, x, fun, it, rows = ctx.solve_raw(lp.InteriorPoint.default().opts(), want_log=True)
+    assert rc == 0 and 4 <= it <= 15
+    assert rows[-1][1] < 1e-8 and rows[-1][2] < 1e-8 and rows[-1][3] < 1e-8      # rho_p, rho_d, rho_A < tol
+    assert np.abs(A @ x - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+    assert x.min() > -1e-9 and np.abs(x - xstar).max() < 1e-3
+    assert abs(fun - c @ xstar) <= 1e-6 * abs(c @ xstar)
+    ctx.upload_arrays(A[:128, :256].copy(), b[:128].copy(), c[:256].copy())      # release the 7 GiB of buffers
