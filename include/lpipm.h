@@ -41,7 +41,7 @@ typedef enum {
     LPIPM_ITERATION_LIMIT         = 7, /* error.rs:28  IterationLimitExceeded(x / tau): x_out IS filled */
     LPIPM_ERR_HIP                 = 100, /* HIP runtime failure (lpipm_last_error_detail has the text) */
     LPIPM_ERR_NO_PROBLEM          = 101, /* solve before upload */
-    LPIPM_ERR_UNSUPPORTED         = 102, /* valid in the reference, not built here yet */
+    LPIPM_ERR_UNSUPPORTED         = 102, /* valid in the reference, not built here (QR arms beyond m = 16384) */
     LPIPM_ERR_BAD_ARGUMENT        = 103  /* null pointer / lda < n / size overflow */
 } lpipm_status;
 
@@ -161,6 +161,12 @@ int lpipm_k_potrf(lpipm_ctx* ctx, uint64_t m, double* M_inout, int32_t* info_out
  * L = the factor of a preceding lpipm_k_potrf on this ctx (kept on device).  R, V: nrhs x m. */
 int lpipm_k_chol_solve(lpipm_ctx* ctx, uint64_t m, int nrhs, const double* R, double* V,
                        int repeats, double* ms_out);
+/* newton_equations.rs:133-149, :155-166 (the Inverse / LeastSquares arms): V[r] = R^-1 Q^T R[r] with
+ * M = QR a Householder factorisation of the symmetric m x m matrix M (row-major; only the lower
+ * triangle is read), nrhs 1|2, m <= 16384.  info_out: 0, or k+1 for a zero column / zero R[k][k].
+ * ms_out: device time of factorisation + solves. */
+int lpipm_k_qr_solve(lpipm_ctx* ctx, uint64_t m, const double* M, int nrhs, const double* R, double* V,
+                     int32_t* info_out, double* ms_out);
 /* A.w (feasible_point.rs:122, newton_equations.rs:220, residual.rs:23): nrhs (1|2) vectors,
  * W nrhs x n -> Y nrhs x m. */
 int lpipm_k_gemv_n(lpipm_ctx* ctx, int nrhs, const double* W, double* Y, int repeats, double* ms_out);

@@ -294,6 +294,15 @@ class Context:
         _raise_for(_capi.lib().lpipm_k_chol_solve(self._h, m, R.shape[0], _p(R), _p(V), repeats, C.byref(ms)))
         return V, ms.value
 
+    def k_qr_solve(self, M, R):
+        M = _f64(M)
+        R = np.atleast_2d(_f64(R))
+        V = np.empty_like(R)
+        info, ms = C.c_int32(0), C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_qr_solve(self._h, M.shape[0], _p(M), R.shape[0], _p(R), _p(V), C.byref(info),
+                                                C.byref(ms)))
+        return V, info.value, ms.value
+
     def k_gemv_n(self, W, repeats=1):
         W = np.atleast_2d(_f64(W))
         Y = np.empty((W.shape[0], self.m))

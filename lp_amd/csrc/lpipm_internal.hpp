@@ -102,6 +102,15 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
 hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan, int nrhs, double* R,
                              double* Yscratch, hipStream_t st);
 
+// ---------------------------------------------------------------- QR arms (kernels_qr.hip)
+// EquationSolverType::{Inverse, LeastSquares}: Householder QR of the full mp x mp matrix whose LOWER
+// triangle is in M (the upper one is filled in first); reflectors below the diagonal, R on and above,
+// tau[mp].  info: 0, or 1 + index of a zero column / zero R diagonal.
+hipError_t launch_qr_factor(double* M, int64_t ld, int mp, double* tau, int32_t* info, hipStream_t st);
+// R[q] <- R^-1 Q^T R[q] in place, q < nrhs (row stride mp); mp <= 16384
+hipError_t launch_qr_solve(const double* M, int64_t ld, int mp, const double* tau, int nrhs, double* R,
+                           int32_t* info, hipStream_t st);
+
 // ---------------------------------------------------------------- GEMV (kernels_gemv.hip)
 // Y[r][i] = (add[r] ? add[r][i] : 0) + alpha * sum_k A[i][k] * W[r][k],   i < m, k < np
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,

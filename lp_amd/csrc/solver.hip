@@ -50,6 +50,7 @@ struct lpipm_ctx {
     std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
     // problem + state + work
     FactorPlan plan, kplan;
+    double *tau = nullptr, *ktau = nullptr;   // Householder scalars of the QR arms
     double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
     int2* tile_list = nullptr;
     int ntiles = 0, adat_nwg = 1;
@@ -59,6 +60,7 @@ struct lpipm_ctx {
     double *kM = nullptr, *kM0 = nullptr, *kR = nullptr, *kY = nullptr;
     int32_t* kinfo = nullptr;
     int kmp = 0;
+    bool kchol_valid = false;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -284,6 +286,7 @@ extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const do
         LP_TRY(dalloc(L, &c->alloc_bytes, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.flags, 1, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->M, (size_t)mp * mp, st));
         LP_HIP(factor_plan_create(c->plan, c->M, mp, mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->tau, (size_t)mp, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->xout, (size_t)np, st));
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
@@ -360,12 +363,15 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_VEC);
     LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
     prof_mark(c, T_ADAT);
-    LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
+    const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
+    if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
+    else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
     LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R));  // :220
     prof_mark(c, T_GEMV);
-    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));                     // :221
+    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));           // :221, :154
+    else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 2, v.R, v.potrf_info, st));   // :155-166
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 2, v.R));                  // :223
     prof_mark(c, T_GEMV);
@@ -376,7 +382,8 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     // corrector: only the second sym_solve changes
     LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R));
     prof_mark(c, T_GEMV);
-    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
+    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
+    else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 1, v.R, v.potrf_info, st));
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 1, v.R));
     prof_mark(c, T_GEMV);
@@ -402,7 +409,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
     if (o->solver_type < 0 || o->solver_type > 2) return LPIPM_INVALID_PARAMETER;
     if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
-    if (o->solver_type != LPIPM_SOLVER_CHOLESKY) return LPIPM_ERR_UNSUPPORTED;  // DESIGN.md, SURVEY 8(f)1
+    if (o->solver_type != LPIPM_SOLVER_CHOLESKY && c->mp > 16384) return LPIPM_ERR_UNSUPPORTED;  // QR solve keeps the rhs in LDS
     LP_HIP(hipSetDevice(c->device));
     VecArgs& v = c->va;
     hipStream_t st = c->st;
@@ -595,6 +602,7 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kR, (size_t)2 * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kY, (size_t)2 * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
+    LP_TRY(dalloc(c->kallocs, nullptr, &c->ktau, (size_t)mp, c->st));
     LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, c->st));
     c->kmp = mp;
     return LPIPM_OK;
@@ -649,6 +657,7 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
                             hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
     if (info_out) *info_out = info;
+    c->kchol_valid = true;
     return LPIPM_OK;
 }
 
@@ -656,7 +665,7 @@ extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const doub
                                   double* ms_out) {
     if (!c || !R || !V || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
     const int mp = (int)round_up(m, NB);
-    if (c->kmp != mp) return LPIPM_ERR_NO_PROBLEM;  // needs a preceding lpipm_k_potrf of this size
+    if (c->kmp != mp || !c->kchol_valid) return LPIPM_ERR_NO_PROBLEM;  // needs a preceding lpipm_k_potrf of this size
     LP_HIP(hipSetDevice(c->device));
     if (repeats < 1) repeats = 1;
     float total = 0.f;
@@ -676,6 +685,39 @@ extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const doub
     LP_HIP(hipMemcpy2DAsync(V, m * sizeof(double), c->kR, (size_t)mp * sizeof(double), m * sizeof(double), nrhs,
                             hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_qr_solve(lpipm_ctx* c, uint64_t m, const double* M, int nrhs, const double* R, double* V,
+                                int32_t* info_out, double* ms_out) {
+    if (!c || !M || !R || !V || m == 0 || m > 16384 || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipSetDevice(c->device));
+    const int mp = (int)round_up(m, NB);
+    LP_TRY(kbuf_ensure(c, mp));
+    std::vector<double> pad((size_t)(mp - m), 1.0);
+    LP_HIP(hipMemsetAsync(c->kM, 0, (size_t)mp * mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpy2DAsync(c->kM, (size_t)mp * sizeof(double), M, m * sizeof(double), m * sizeof(double), m,
+                            hipMemcpyHostToDevice, c->st));
+    if (mp > (int)m)
+        LP_HIP(hipMemcpy2DAsync(c->kM + m * mp + m, (size_t)(mp + 1) * sizeof(double), pad.data(), sizeof(double),
+                                sizeof(double), mp - m, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemsetAsync(c->kR, 0, (size_t)2 * mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpy2DAsync(c->kR, (size_t)mp * sizeof(double), R, m * sizeof(double), m * sizeof(double), nrhs,
+                            hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipEventRecord(c->ev_begin, c->st));
+    LP_HIP(launch_qr_factor(c->kM, mp, mp, c->ktau, c->kinfo, c->st));
+    LP_HIP(launch_qr_solve(c->kM, mp, mp, c->ktau, nrhs, c->kR, c->kinfo, c->st));
+    LP_HIP(hipEventRecord(c->ev_end, c->st));
+    int32_t info = 0;
+    LP_HIP(hipMemcpyAsync(&info, c->kinfo, sizeof(int32_t), hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipMemcpy2DAsync(V, m * sizeof(double), c->kR, (size_t)mp * sizeof(double), m * sizeof(double), nrhs,
+                            hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    float ms = 0.f;
+    LP_HIP(hipEventElapsedTime(&ms, c->ev_begin, c->ev_end));
+    if (ms_out) *ms_out = ms;
+    if (info_out) *info_out = info;
+    c->kchol_valid = false;   // kM no longer holds a Cholesky factor: lpipm_k_chol_solve needs a new lpipm_k_potrf
     return LPIPM_OK;
 }
 

@@ -80,9 +80,11 @@ static void gpu_tests() {
     {   // test_linprog_ub_only, mod.rs:332-344
         CHECK(close(InteriorPoint::default_().solve(Problem::target(c3).ub(A3, b3).build()).x(), {0.5, 0.0, 1.25}, 1e-6));
     }
-    {   // Inverse / LeastSquares arms (mod.rs:275-317) are not built yet: the backend must say so, loudly
-        try { InteriorPoint::custom().solver_type(EquationSolverType::Inverse).build().solve(make_problem()); CHECK(false); }
-        catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Backend); }
+    {   // test_interior_point_inverse_solver / _least_squares_solver, mod.rs:275-317
+        CHECK(close(InteriorPoint::custom().solver_type(EquationSolverType::Inverse).build().solve(make_problem()).x(),
+                    {1, 0}, 1e-6));
+        CHECK(close(InteriorPoint::custom().solver_type(EquationSolverType::LeastSquares).build().solve(make_problem()).x(),
+                    {1, 0}, 1e-6));
     }
     {   // exits the reference defines but never tests: indicators.rs:66-83, mod.rs:232-239
         Matrix Ae = mat({1, 1}, 1, 2);

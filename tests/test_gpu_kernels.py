@@ -125,3 +125,22 @@ def test_adat_linearity_full_size(ctx):
 def test_mfma_probe_runs(ctx):
     tf, ms = ctx.k_mfma_f64_probe(2000)
     assert tf > 1.0 and ms > 0.0
+
+
+@pytest.mark.parametrize("m", [3, 64, 130, 300])
+def test_qr_solve(ctx, m):
+    """newton_equations.rs:133-149,155-166 (QR arms): R^-1 Q^T r against numpy.linalg.solve on a symmetric,
+    NOT positive definite matrix (the arms must not depend on definiteness); singular input is reported."""
+    rng = np.random.default_rng(m)
+    B = rng.standard_normal((m, m))
+    M = B + B.T                                  # symmetric indefinite
+    R = rng.standard_normal((2, m))
+    V, info, _ = ctx.k_qr_solve(M, R)
+    assert info == 0
+    ref = np.linalg.solve(M, R.T).T
+    assert np.abs(V - ref).max() <= 1e-9 * np.abs(ref).max() * max(1.0, np.linalg.cond(M) / 1e4)
+    Ms = M.copy()
+    Ms[:, 1] = 0.0
+    Ms[1, :] = 0.0
+    _, info, _ = ctx.k_qr_solve(Ms, R[:1])
+    assert info != 0

@@ -82,14 +82,23 @@ def test_readme_trajectory_matches_oracle(built):
     assert np.abs(got[:, 1:6] / exp[:, 1:6] - 1.0).max() < 1e-3   # still the same order at 1e-11
 
 
-def test_unsupported_solver_types_fail_loudly(built):
-    """Inverse / LeastSquares (newton_equations.rs:133-149) are SURVEY 8(f) "next" rows: the HIP backend
-    must refuse them, not fall back to anything."""
+def test_inverse_and_least_squares_arms(built):
+    """test_interior_point_inverse_solver / _least_squares_solver (interior_point/mod.rs:275-317): README LP,
+    expected [1, 0] within 1e-6; plus a planted LP against the oracle's QR arms (same iterations, 1e-6)."""
     import lp_amd as lp
+    from lp_amd import synth
+    from oracle import capi as oracle
     prob = _readme_problem(lp)
     for st in (lp.EquationSolverType.Inverse, lp.EquationSolverType.LeastSquares):
-        with pytest.raises(lp.BackendError):
-            lp.InteriorPoint.custom().solver_type(st).build().solve(prob)
+        res = lp.InteriorPoint.custom().solver_type(st).build().solve(prob)
+        assert np.abs(res.x() - np.array([1.0, 0.0])).max() < 1e-6 and res.iteration() == 4
+    A, b, c, _ = synth.planted_lp(4, 150, 310)
+    ctx = lp.default_context(0).upload_arrays(A, b, c)
+    for st in (1, 2):
+        rc, x, fun, it, _ = ctx.solve_raw(lp.InteriorPoint.custom().solver_type(st).build().opts())
+        ref = oracle.solve(A, b, c, 0.0, oracle.default_opts(solver_type=st))
+        assert rc == 0 == ref["status"] and it == ref["iterations"]
+        assert np.abs(x - ref["x_slack"]).max() <= X_TOL
 
 
 def test_infeasible_unbounded_iteration_limit(built):
