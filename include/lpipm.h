@@ -136,6 +136,22 @@ int lpipm_solve_batch(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const u
                       const double* c0, const lpipm_opts* opts, double* const* x_slack_out,
                       double* fun_out, uint64_t* iterations_out, int32_t* status_out);
 
+/* ---- one LP split by COLUMNS over several ranks / GPUs (BASELINE config C5) -----------------------------
+ * Rank g holds the column block A[:, J_g] (m x n_local), c[J_g] and the matching slices of x, z; b and y
+ * are replicated.  Per iteration the partial normal equations M_g = A_g D_g A_g^T are summed over ranks
+ * (the "all-reduce on A.D.A^T panels"), as are A_g.w_g (m doubles) and a handful of dot products / ratio-test
+ * minima; the factorisation runs replicated on every rank.  The library never links a communication
+ * library: the caller supplies the all-reduce (RCCL `ncclAllReduce` on `stream` from Rust/C++, a
+ * torch.distributed call from the Python harness).
+ *   fn(user, dev_ptr, count, op, stream): in-place all-reduce of `count` doubles at device pointer dev_ptr,
+ *   op 0 = sum, 1 = min; the stream has been drained before the call; return 0 when the result is in place. */
+typedef int (*lpipm_allreduce_fn)(void* user, void* dev_ptr, uint64_t count, int op, void* stream);
+int lpipm_set_collective(lpipm_ctx* ctx, int rank, int world, lpipm_allreduce_fn fn, void* user);
+/* Upload this rank's column block; afterwards lpipm_solve / lpipm_solve_device run the n-split algorithm and
+ * return this rank's slice of x / tau (n_local doubles); fun, iterations and the log are global. */
+int lpipm_upload_nsplit(lpipm_ctx* ctx, uint64_t m, uint64_t n_total, uint64_t n_local, const double* A_local,
+                        uint64_t lda, const double* b, const double* c_local, double c0);
+
 /* Number of LPs of a batch in flight at once on the device (0 = auto, the default: 8 for members up
  * to m = 2048, else 2; 1 = strictly one after the other).  Members of a batch are independent, each in-flight member has its own stream and buffers. */
 int lpipm_set_batch_concurrency(lpipm_ctx* ctx, int nworkers);

@@ -247,6 +247,24 @@ class Context:
         self.m, self.n = m, n
         return self
 
+    def set_collective(self, rank: int, world: int, collective):
+        """`collective.cfn` is an lpipm_allreduce_fn thunk (lp_amd.colsplit.TorchCollective); kept alive here."""
+        self._collective = collective
+        cfn = C.cast(collective.cfn, C.c_void_p) if collective is not None else None
+        _raise_for(_capi.lib().lpipm_set_collective(self._h, int(rank), int(world), cfn, None))
+        return self
+
+    def upload_column_block(self, A_local, b, c_local, n_total: int, c0=0.0):
+        """This rank's columns of one LP split over ranks (lpipm_upload_nsplit); solve_raw then returns
+        this rank's slice of x."""
+        A, b, c = _f64(A_local), _f64(b), _f64(c_local)
+        if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
+            raise IncompatibleInputDimensions()
+        m, nl = A.shape
+        _raise_for(_capi.lib().lpipm_upload_nsplit(self._h, m, int(n_total), nl, _p(A), nl, _p(b), _p(c), float(c0)))
+        self.m, self.n = m, nl
+        return self
+
     def solve_raw(self, opts: "_capi.Opts", want_log: bool = False, x_dev_ptr: int | None = None):
         """-> (status, x_slack | None, fun, iterations, log rows)"""
         x = None if x_dev_ptr is not None else np.full(self.n, np.nan)

@@ -46,6 +46,8 @@ SYMBOLS = {
     "lpipm_solve_device": (C.c_int, [_vp, C.POINTER(Opts), _vp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_batch": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,
                                     C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
+    "lpipm_set_collective": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, _vp]),
+    "lpipm_upload_nsplit": (C.c_int, [_vp, _u64, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
     "lpipm_set_batch_concurrency": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_profiling": (C.c_int, [_vp, C.c_int]),
     "lpipm_get_phase_times": (C.c_int, [_vp, C.POINTER(PhaseTimes)]),
@@ -58,6 +60,8 @@ SYMBOLS = {
     "lpipm_k_mfma_f64_probe": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "lpipm_synth_planted_lp": (C.c_int, [_u64, _u64, _u64, _dp, _dp, _dp, _dp]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)   # lpipm_allreduce_fn
 
 _lib = None
 

@@ -53,6 +53,23 @@ __device__ __forceinline__ double fold_min(const double* red, int slot, int nblk
     return wave_min(s);
 }
 
+// n-split mode: gs[first .. first+count) <- fold of the reduction slots (sum or min), optionally the NaN
+// flag as a number in gs[flag_slot]; the host then reduces gs across ranks.
+__global__ void k_fold(VecArgs a, int first, int count, int is_min, int flag_slot) {
+    for (int s = first; s < first + count; ++s) {
+        const double v = is_min ? fold_min(a.red, s, a.nblk, 1.0) : fold_sum(a.red, s, a.nblk);
+        if (threadIdx.x == 0) a.gs[s] = v;
+    }
+    if (flag_slot >= 0 && threadIdx.x == 0) a.gs[flag_slot] = (*a.flags & FLAG_NAN_PQ) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(256) void k_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0,
+                                                  const double* add1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    if (add0) Y[i] += add0[i];
+    if (nrhs > 1 && add1) Y[ldy + i] += add1[i];
+}
+
 // ---------------------------------------------------------------- FeasiblePoint::blind_start
 // feasible_point.rs:24-31: x = 1, y = 0, z = 1, tau = kappa = 1
 __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
@@ -100,16 +117,17 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
 // from (feasible_point.rs:119-125, rhat.rs:31,33).
 __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol, double c0) {
     const int nblk = a.nblk;
+    // |r_P|^2 and b.y run over m (replicated on every rank); the other four over the (possibly split) n
     const double rp2 = fold_sum(a.red, 0, nblk), by = fold_sum(a.red, 1, nblk);
-    const double rd2 = fold_sum(a.red, 2, nblk), cx = fold_sum(a.red, 3, nblk);
-    const double xz = fold_sum(a.red, 4, nblk), cxt = fold_sum(a.red, 5, nblk);
+    const double rd2 = a.gs ? a.gs[2] : fold_sum(a.red, 2, nblk), cx = a.gs ? a.gs[3] : fold_sum(a.red, 3, nblk);
+    const double xz = a.gs ? a.gs[4] : fold_sum(a.red, 4, nblk), cxt = a.gs ? a.gs[5] : fold_sum(a.red, 5, nblk);
     if (threadIdx.x != 0) return;
     double* S = a.S;
     const double tau = S[S_TAU], kappa = S[S_KAPPA];
     const double rho_p = sqrt(rp2);                                   // residual.rs:34
     const double rho_d = sqrt(rd2);                                   // residual.rs:35
     const double rho_g = fabs(kappa + cx - by);                       // residual.rs:27-29,36
-    const double rho_mu = (xz + tau * kappa) / (double)(a.n + 1);     // residual.rs:30-32,37
+    const double rho_mu = (xz + tau * kappa) / (double)(a.n_total + 1);  // residual.rs:30-32,37
     if (is_init) {                                                    // feasible_point.rs:32
         S[S_RP0] = rho_p; S[S_RD0] = rho_d; S[S_RG0] = rho_g; S[S_RMU0] = rho_mu;
     }
@@ -139,7 +157,7 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
     const double gamma = ip_next ? 1.0 : 0.0;
     const double eta = ip_next ? 1.0 : 1.0 - gamma;
     const double rG = cx - by + kappa;                                // :124
-    const double mu = (xz + tau * kappa) / (double)(a.n + 1);         // :125
+    const double mu = (xz + tau * kappa) / (double)(a.n_total + 1);   // :125
     S[S_RG] = rG; S[S_MU] = mu; S[S_GAMMA] = gamma; S[S_ETA] = eta;
     S[S_RHAT_G] = rG * eta;                                           // rhat.rs:31
     S[S_RHAT_TK] = gamma * mu - tau * kappa;                          // rhat.rs:33
@@ -218,11 +236,12 @@ __global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
 __global__ void k_scalar_dtau(VecArgs a, int phase) {
     const int nblk = a.nblk;
     double cp, cu, bq, bv;
-    if (phase == 0) {
-        cp = fold_sum(a.red, 0, nblk); cu = fold_sum(a.red, 1, nblk);
+    if (phase == 0) {   // c.p, c.u run over the (possibly split) n; b.q, b.v over m (replicated)
+        cp = a.gs ? a.gs[0] : fold_sum(a.red, 0, nblk); cu = a.gs ? a.gs[1] : fold_sum(a.red, 1, nblk);
         bq = fold_sum(a.red, 2, nblk); bv = fold_sum(a.red, 3, nblk);
+        if (a.gs && a.gs[2] > 0.0 && threadIdx.x == 0) atomicOr(a.flags, FLAG_NAN_PQ);   // some rank saw NaN in p
     } else {
-        cu = fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk);
+        cu = a.gs ? a.gs[0] : fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk);
         cp = a.S[S_CP]; bq = a.S[S_BQ];
     }
     if (threadIdx.x != 0) return;
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
 // phase 1: the step length of the iteration (interior_point/mod.rs:216-221).
 __global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
     const int nblk = a.nblk;
-    const double ax = fold_min(a.red, 0, nblk, 1.0), az = fold_min(a.red, 1, nblk, 1.0);
+    const double ax = a.gs ? a.gs[0] : fold_min(a.red, 0, nblk, 1.0), az = a.gs ? a.gs[1] : fold_min(a.red, 1, nblk, 1.0);
     if (threadIdx.x != 0) return;
     double* S = a.S;
     const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA];
@@ -349,7 +368,7 @@ __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
     block_reduce_store<1, false>(acc, a.red, 0);
 }
 __global__ void k_scalar_fun(VecArgs a, double c0) {
-    const double s = fold_sum(a.red, 0, a.nblk);
+    const double s = a.gs ? a.gs[0] : fold_sum(a.red, 0, a.nblk);
     if (threadIdx.x == 0) a.status->obj = s + c0;
 }
 
@@ -357,31 +376,50 @@ __global__ void k_scalar_fun(VecArgs a, double c0) {
 static inline dim3 vgrid(const VecArgs& a) { return dim3(a.nblk); }
 
 void vec_blind_start(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_blind_start, vgrid(a), dim3(256), 0, st, a); }
-void vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st) {
+static int cross(const VecArgs& a, const XRank* xr, int first, int count, int is_min, int flag_slot, int red_first,
+                 int red_count, hipStream_t st) {
+    if (!a.gs || !xr) return 0;
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, st, a, first, count, is_min, flag_slot);
+    return xr->fn(xr->self, a.gs + red_first, red_count, is_min);
+}
+int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);
+    if (int rc = cross(a, xr, 2, 4, 0, -1, 2, 4, st)) return rc;     // |r_D|^2, c.x, x.z, c.(x/tau)
     hipLaunchKernelGGL(k_scalar_indicators, dim3(1), dim3(64), 0, st, a, is_init, ip_next, tol, c0);
+    return 0;
 }
 void vec_pred_setup(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_pred_setup, vgrid(a), dim3(256), 0, st, a); }
-void vec_pq_uv(const VecArgs& a, hipStream_t st) {
+int vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_pq_uv, vgrid(a), dim3(256), 0, st, a);
+    if (int rc = cross(a, xr, 0, 2, 0, 2, 0, 3, st)) return rc;      // c.p, c.u and the NaN-in-p flag (gs[2])
     hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 0);
+    return 0;
 }
-void vec_uv_corr(const VecArgs& a, hipStream_t st) {
+int vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_uv_corr, vgrid(a), dim3(256), 0, st, a);
+    if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.u
     hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 1);
+    return 0;
 }
-void vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st) {
+int vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_delta, vgrid(a), dim3(256), 0, st, a, phase);
+    if (int rc = cross(a, xr, 0, 2, 1, -1, 0, 2, st)) return rc;     // ratio-test minima over x and z
     hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(64), 0, st, a, phase, ip, alpha0);
+    return 0;
 }
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) { hipLaunchKernelGGL(k_corr_setup, vgrid(a), dim3(256), 0, st, a, ip); }
 void vec_step(const VecArgs& a, int ip, hipStream_t st) {
     hipLaunchKernelGGL(k_step, vgrid(a), dim3(256), 0, st, a, ip);
     hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(64), 0, st, a, ip);
 }
-void vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st) {
+int vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_final_x, vgrid(a), dim3(256), 0, st, a, xout);
+    if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.(x/tau)
     hipLaunchKernelGGL(k_scalar_fun, dim3(1), dim3(64), 0, st, a, c0);
+    return 0;
+}
+void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st) {
+    hipLaunchKernelGGL(k_add_rows, dim3((m + 255) / 256), dim3(256), 0, st, m, nrhs, Y, ldy, add0, add1);
 }
 
 }  // namespace lpipm

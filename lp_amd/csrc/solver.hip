@@ -72,7 +72,27 @@ struct lpipm_ctx {
     // batch mode: extra contexts (own stream + buffers) driven by host threads, see lpipm_solve_batch
     std::vector<lpipm_ctx*> workers;
     int batch_concurrency = 0;   // 0 = auto
+    // n-split mode (one LP split by columns over ranks; BASELINE config C5): the collective is the caller's
+    bool colsplit = false;
+    int rank = 0, world = 1;
+    lpipm_allreduce_fn coll = nullptr;
+    void* coll_user = nullptr;
+    double* gs = nullptr;        // 8 doubles: sums / minima that must be reduced across ranks
 };
+
+// Cross-rank reduction of `count` doubles at a device pointer, ordered after everything enqueued on the
+// ctx's stream so far (the stream is drained first; the callee returns when the result is in place).
+static int ctx_allreduce(lpipm_ctx* c, double* ptr, uint64_t count, int op) {
+    if (!c->colsplit || c->world <= 1) return LPIPM_OK;
+    if (!c->coll) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipStreamSynchronize(c->st));
+    if (c->coll(c->coll_user, ptr, count, op, (void*)c->st) != 0) {
+        g_err_detail = "the all-reduce callback of lpipm_set_collective reported a failure";
+        return LPIPM_ERR_HIP;
+    }
+    return LPIPM_OK;
+}
+static int xrank_fn(void* self, double* ptr, int count, int op) { return ctx_allreduce((lpipm_ctx*)self, ptr, (uint64_t)count, op); }
 
 // ------------------------------------------------------------------------------------------------
 static int free_list(std::vector<void*>& v) {
@@ -287,6 +307,7 @@ extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const do
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->M, (size_t)mp * mp, st));
         LP_HIP(factor_plan_create(c->plan, c->M, mp, mp, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->tau, (size_t)mp, st));
+        LP_TRY(dalloc(L, &c->alloc_bytes, &c->gs, (size_t)8, st));
         LP_TRY(dalloc(L, &c->alloc_bytes, &c->xout, (size_t)np, st));
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
@@ -307,6 +328,7 @@ extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const do
     c->m = m; c->n = n; c->c0 = c0;
     c->ns = (int)n_slack; c->nx = (int)nx;
     c->va.n = (int)n; c->va.m = (int)m;
+    c->va.n_total = (long long)n; c->va.gs = nullptr; c->colsplit = false;   // lpipm_upload_nsplit overrides
     LP_HIP(hipMemcpy2DAsync(c->A, (size_t)npa * sizeof(double), A, (size_t)lda * sizeof(double),
                             (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->st));
     LP_HIP(hipMemcpyAsync((void*)c->va.b, b, m * sizeof(double), hipMemcpyHostToDevice, c->st));
@@ -345,10 +367,12 @@ static hipError_t run_adat(lpipm_ctx* c) {
 static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol) {
     VecArgs& v = c->va;
     // A.x and A^T.y at the current point (residual.rs:23,25)
+    XRank xr{xrank_fn, c};
     LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax));
+    LP_TRY(ctx_allreduce(c, v.Ax, c->m, 0));          // n-split: A.x = sum over ranks of A_g.x_g
     LP_HIP(ctx_gemv_t(c, 1, v.y));
     prof_mark(c, T_GEMV);
-    vec_residuals(v, is_init, ip_next, tol, c->c0, c->st);
+    LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->c0, c->st, c->colsplit ? &xr : nullptr));
     LP_HIP(hipGetLastError());
     return LPIPM_OK;
 }
@@ -361,34 +385,49 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_VEC);
     vec_pred_setup(v, st);
     prof_mark(c, T_VEC);
+    XRank xr_{xrank_fn, c};
+    const XRank* xr = c->colsplit ? &xr_ : nullptr;
     LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
+    LP_TRY(ctx_allreduce(c, c->M, (uint64_t)c->mp * c->mp, 0));            // n-split: M = sum_g A_g D_g A_g^T
     prof_mark(c, T_ADAT);
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
     else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
-    LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R));  // :220
+    if (!c->colsplit) {
+        LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R));  // :220
+    } else {   // the addend r2 enters once, after the cross-rank sum of the column-split products
+        LP_HIP(ctx_gemv_n(c, 2, v.W, nullptr, nullptr, v.R));
+        LP_TRY(ctx_allreduce(c, v.R, (uint64_t)2 * c->mp, 0));
+        vec_add_rows((int)c->m, 2, v.R, c->mp, v.b, v.rP, st);
+    }
     prof_mark(c, T_GEMV);
     if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));           // :221, :154
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 2, v.R, v.potrf_info, st));   // :155-166
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 2, v.R));                  // :223
     prof_mark(c, T_GEMV);
-    vec_pq_uv(v, st);                       // :223, delta.rs:29-32,38
-    vec_delta(v, 0, ip, 1.0, st);           // delta.rs:33-37, feasible_point.rs:134-136
+    LP_TRY(vec_pq_uv(v, st, xr));                       // :223, delta.rs:29-32,38
+    LP_TRY(vec_delta(v, 0, ip, 1.0, st, xr));           // delta.rs:33-37, feasible_point.rs:134-136
     vec_corr_setup(v, ip, st);              // rhat.rs:37-75
     prof_mark(c, T_VEC);
     // corrector: only the second sym_solve changes
-    LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R));
+    if (!c->colsplit) {
+        LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R));
+    } else {
+        LP_HIP(ctx_gemv_n(c, 1, v.W, nullptr, nullptr, v.R));
+        LP_TRY(ctx_allreduce(c, v.R, c->mp, 0));
+        vec_add_rows((int)c->m, 1, v.R, c->mp, v.rP2, nullptr, st);
+    }
     prof_mark(c, T_GEMV);
     if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 1, v.R, v.potrf_info, st));
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 1, v.R));
     prof_mark(c, T_GEMV);
-    vec_uv_corr(v, st);
-    vec_delta(v, 1, ip, o->alpha0, st);     // mod.rs:216-221
+    LP_TRY(vec_uv_corr(v, st, xr));
+    LP_TRY(vec_delta(v, 1, ip, o->alpha0, st, xr));     // mod.rs:216-221
     vec_step(v, ip, st);                    // feasible_point.rs:76-106
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
@@ -455,7 +494,8 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     }
     if (ret == LPIPM_ITERATION_LIMIT) iteration = o->max_iter;
     if (ret == LPIPM_OK || ret == LPIPM_ITERATION_LIMIT) {
-        vec_final_x(v, c->xout, c->c0, st);                        // mod.rs:231/238, :165
+        XRank xrf{xrank_fn, c};
+        LP_TRY(vec_final_x(v, c->xout, c->c0, st, c->colsplit ? &xrf : nullptr));   // mod.rs:231/238, :165
         LP_HIP(hipGetLastError());
         if (x_dev) LP_HIP(hipMemcpyAsync(x_dev, c->xout, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
         if (x_host) LP_HIP(hipMemcpyAsync(x_host, c->xout, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -546,6 +586,23 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
 extern "C" int lpipm_set_batch_concurrency(lpipm_ctx* c, int nworkers) {
     if (!c || nworkers < 0 || nworkers > 64) return LPIPM_ERR_BAD_ARGUMENT;
     c->batch_concurrency = nworkers;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_set_collective(lpipm_ctx* c, int rank, int world, lpipm_allreduce_fn fn, void* user) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return LPIPM_ERR_BAD_ARGUMENT;
+    c->rank = rank; c->world = world; c->coll = fn; c->coll_user = user;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_upload_nsplit(lpipm_ctx* c, uint64_t m, uint64_t n_total, uint64_t n_local, const double* A_local,
+                                   uint64_t lda, const double* b, const double* c_local, double c0) {
+    if (!c || n_local == 0 || n_local > n_total) return LPIPM_ERR_BAD_ARGUMENT;
+    const int rc = lpipm_upload_slack(c, m, n_local, A_local, lda, b, c_local, c0, 0);
+    if (rc != LPIPM_OK) return rc;
+    c->colsplit = true;
+    c->va.n_total = (long long)n_total;
+    c->va.gs = c->gs;
     return LPIPM_OK;
 }
 

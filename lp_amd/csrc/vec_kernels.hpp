@@ -23,6 +23,8 @@ struct StatusRec {
 
 struct VecArgs {
     int n, m, np, mp, nblk, nsplit;
+    long long n_total;   // columns of the WHOLE LP (== n unless the LP is split by columns over ranks)
+    double* gs;          // n-split mode: globally reduced sums / mins the scalar kernels read instead of `red`
     // problem
     const double *b, *c;
     // iterate
@@ -39,15 +41,24 @@ struct VecArgs {
     int *flags;
 };
 
+// n-split mode (a.gs != nullptr): between a vector kernel and the scalar kernel that consumes its
+// partial sums, the sums over the split dimension are folded into a.gs and handed to `xr` for the
+// cross-rank reduction (op 0 = sum, 1 = min); xr == nullptr / a.gs == nullptr: single-GPU path.
+struct XRank {
+    int (*fn)(void* self, double* dev_ptr, int count, int op);
+    void* self;
+};
 void vec_blind_start(const VecArgs& a, hipStream_t st);
-void vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st);
+int  vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st, const XRank* xr = nullptr);
 void vec_pred_setup(const VecArgs& a, hipStream_t st);
-void vec_pq_uv(const VecArgs& a, hipStream_t st);
-void vec_uv_corr(const VecArgs& a, hipStream_t st);
-void vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st);
+int  vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
+int  vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
+int  vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr = nullptr);
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
 void vec_step(const VecArgs& a, int ip, hipStream_t st);
-void vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st);
+int  vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const XRank* xr = nullptr);
+// Y[q][i] += add_q[i] (i < m): the addend of a column-split A.w after its cross-rank sum
+void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st);
 
 
 }  // namespace lpipm

@@ -67,3 +67,14 @@ def test_sharded_batch_two_gloo_ranks(built):
         assert st == ref["status"] == 0 and it == ref["iterations"]
         assert np.abs(np.array(x) - ref["x_slack"]).max() == 0.0 and fun == ref["fun"]
     assert got[0][2][5][0] == oracle.INFEASIBLE and got[0][2][5][2] is None
+
+
+def test_column_range_partitions():
+    from lp_amd.colsplit import column_range
+    for n in (1, 127, 128, 333, 8192, 32768 + 5):
+        for world in (1, 2, 3, 8):
+            for align in (64, 128):
+                got = [j for r in range(world) for j in column_range(n, world, r, align)]
+                assert got == list(range(n))
+                starts = [column_range(n, world, r, align).start for r in range(world)]
+                assert all(s % align == 0 or s == n for s in starts)

@@ -1,0 +1,100 @@
+"""One LP split by columns over ranks (BASELINE config C5 shape class): N gloo ranks, all on
+cuda:0, each holding a column block; the library's cross-rank reductions go through the callback of
+lpipm_set_collective.  Checked against the oracle (same iteration count, |dx| <= 1e-6) and against the
+single-context solve of the same LP."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q, seed, m, n, align):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import lp_amd
+    from lp_amd import synth
+    from lp_amd.colsplit import column_range, solve_column_split
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b, c = synth.planted_lp(seed, m, n)[:3]
+    cols = column_range(n, world, rank, align)
+    opts = lp_amd.InteriorPoint.default().opts()
+    rc, x, fun, it, rows, coll = solve_column_split(np.ascontiguousarray(A[:, cols.start:cols.stop]), b,
+                                                    c[cols.start:cols.stop], n, 0.0, opts, want_log=True)
+    q.put((rank, rc, cols.start, x.tolist(), fun, it, rows, coll.calls, coll.bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, seed, m, n, align=128):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 7 + world * 131 + m) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, seed, m, n, align)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("world,seed,m,n,align", [(2, 0, 256, 512, 128), (3, 1, 100, 333, 64), (2, 3, 512, 1280, 128)])
+def test_column_split_matches_oracle_and_single(ctx, world, seed, m, n, align):
+    import lp_amd
+    from lp_amd import synth
+    from oracle import capi as oracle
+    got = _run(world, seed, m, n, align)
+    A, b, c = synth.planted_lp(seed, m, n)[:3]
+    ref = oracle.solve(A, b, c)
+    ctx.upload_arrays(A, b, c)
+    rc1, x1, fun1, it1, _ = ctx.solve_raw(lp_amd.InteriorPoint.default().opts())
+    assert rc1 == 0 and ref["status"] == 0
+    x = np.full(n, np.nan)
+    for rank, rc, lo, xs, fun, it, rows, calls, nbytes in got:
+        assert rc == 0
+        assert it == ref["iterations"] == it1                      # same trajectory length on every rank
+        assert abs(fun - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
+        assert fun == got[0][4] and rows == got[0][6]              # replicated scalars are bit-identical across ranks
+        x[lo:lo + len(xs)] = xs
+        # per iteration: M, 2 x (A w), 6 scalar groups; plus the residual / final ones
+        assert calls >= 9 * it
+    assert not np.isnan(x).any()
+    assert np.abs(x - ref["x_slack"]).max() <= 1e-6
+    assert np.abs(x - x1).max() <= 1e-6
+
+
+def test_column_split_world_one_is_the_plain_solve(ctx):
+    """world = 1 through the n-split entry points (no callback needed) walks the same code with gs reductions
+    local: must reproduce the plain solve bit for bit."""
+    import lp_amd
+    from lp_amd import synth
+    A, b, c = synth.planted_lp(5, 192, 448)[:3]
+    opts = lp_amd.InteriorPoint.default().opts()
+    ctx.upload_arrays(A, b, c)
+    rc0, x0, f0, it0, _ = ctx.solve_raw(opts)
+    ctx.set_collective(0, 1, None)
+    ctx.upload_column_block(A, b, c, A.shape[1])
+    rc1, x1, f1, it1, _ = ctx.solve_raw(opts)
+    ctx.upload_arrays(A, b, c)                                     # back to the plain mode for later tests
+    assert (rc0, it0) == (rc1, it1) == (0, it0)
+    assert np.array_equal(x0, x1) and f0 == f1
+
+
+def test_column_split_infeasible_agrees_on_all_ranks(ctx):
+    """Control flow (status decisions) must be identical on every rank or the collectives would deadlock."""
+    import lp_amd
+    A = np.array([[1.0, 1.0, 1.0, 1.0]]); b = np.array([-1.0]); c = np.ones(4)
+    ctx.set_collective(0, 1, None)
+    ctx.upload_column_block(A, b, c, 4)
+    rc, _, _, _, _ = ctx.solve_raw(lp_amd.InteriorPoint.default().opts())
+    ctx.upload_arrays(A, b, c)
+    assert rc == lp_amd._capi.INFEASIBLE
