@@ -70,6 +70,18 @@ __global__ __launch_bounds__(256) void k_add_rows(int m, int nrhs, double* Y, lo
     if (nrhs > 1 && add1) Y[ldy + i] += add1[i];
 }
 
+// Lower block-triangle of M (128-row block i keeps columns [0, 128(i+1))) <-> one contiguous buffer, so
+// that the cross-rank sum of the partial normal equations moves m(m+128)/2 doubles instead of m^2.
+// One workgroup per row; dir 0 = pack, 1 = unpack.
+__global__ __launch_bounds__(256) void k_pack_lower(double* __restrict__ M, long long ld, double* __restrict__ P, int dir) {
+    const int row = blockIdx.x, bi = row >> 7;
+    const long long w = (long long)(bi + 1) * 128;
+    double2* p = reinterpret_cast<double2*>(P + 8192ll * bi * (bi + 1) + (long long)(row & 127) * w);
+    double2* q = reinterpret_cast<double2*>(M + (long long)row * ld);
+    if (dir == 0) for (int j = threadIdx.x; j < w / 2; j += 256) p[j] = q[j];
+    else          for (int j = threadIdx.x; j < w / 2; j += 256) q[j] = p[j];
+}
+
 // ---------------------------------------------------------------- FeasiblePoint::blind_start
 // feasible_point.rs:24-31: x = 1, y = 0, z = 1, tau = kappa = 1
 __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
@@ -417,6 +429,9 @@ int vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const
     if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.(x/tau)
     hipLaunchKernelGGL(k_scalar_fun, dim3(1), dim3(64), 0, st, a, c0);
     return 0;
+}
+void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_lower, dim3(mp), dim3(256), 0, st, M, ld, packed, dir);
 }
 void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st) {
     hipLaunchKernelGGL(k_add_rows, dim3((m + 255) / 256), dim3(256), 0, st, m, nrhs, Y, ldy, add0, add1);

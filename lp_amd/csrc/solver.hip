@@ -78,6 +78,8 @@ struct lpipm_ctx {
     lpipm_allreduce_fn coll = nullptr;
     void* coll_user = nullptr;
     double* gs = nullptr;        // 8 doubles: sums / minima that must be reduced across ranks
+    double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
+    size_t mpack_count = 0;
 };
 
 // Cross-rank reduction of `count` doubles at a device pointer, ordered after everything enqueued on the
@@ -224,6 +226,7 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     free_list(c->allocs);
     free_list(c->kallocs);
+    if (c->mpack) (void)hipFree(c->mpack);
     factor_plan_destroy(c->plan);
     factor_plan_destroy(c->kplan);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -388,7 +391,11 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     XRank xr_{xrank_fn, c};
     const XRank* xr = c->colsplit ? &xr_ : nullptr;
     LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
-    LP_TRY(ctx_allreduce(c, c->M, (uint64_t)c->mp * c->mp, 0));            // n-split: M = sum_g A_g D_g A_g^T
+    if (c->colsplit && c->world > 1) {                                     // n-split: M = sum_g A_g D_g A_g^T
+        vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
+        LP_TRY(ctx_allreduce(c, c->mpack, c->mpack_count, 0));
+        vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 1, st);
+    }
     prof_mark(c, T_ADAT);
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
@@ -600,6 +607,14 @@ extern "C" int lpipm_upload_nsplit(lpipm_ctx* c, uint64_t m, uint64_t n_total, u
     if (!c || n_local == 0 || n_local > n_total) return LPIPM_ERR_BAD_ARGUMENT;
     const int rc = lpipm_upload_slack(c, m, n_local, A_local, lda, b, c_local, c0, 0);
     if (rc != LPIPM_OK) return rc;
+    if (c->world > 1) {
+        const size_t need = (size_t)c->mp * ((size_t)c->mp + 128) / 2;
+        if (need != c->mpack_count) {
+            if (c->mpack) { LP_HIP(hipFree(c->mpack)); c->mpack = nullptr; c->mpack_count = 0; }
+            LP_HIP(hipMalloc((void**)&c->mpack, need * sizeof(double)));
+            c->mpack_count = need;
+        }
+    }
     c->colsplit = true;
     c->va.n_total = (long long)n_total;
     c->va.gs = c->gs;

@@ -58,6 +58,8 @@ void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
 void vec_step(const VecArgs& a, int ip, hipStream_t st);
 int  vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const XRank* xr = nullptr);
 // Y[q][i] += add_q[i] (i < m): the addend of a column-split A.w after its cross-rank sum
+// packed has mp*(mp+128)/2 doubles; dir 0 = M -> packed, 1 = packed -> M (mp a multiple of 128, ld even)
+void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st);
 void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st);
 
 
