@@ -44,7 +44,15 @@ struct GemmK {
     int diag_pad_from;
     double* ws;
     int nwg;
+    BatchK bk;
 };
+// LP blockIdx.z of a lockstep batch: per-LP pointers shifted (the tile list is shared)
+__device__ __forceinline__ GemmK batch_shift(const GemmK& p0) {
+    GemmK p = p0;
+    p.P = batch_ptr(p0.P, p0.bk); p.Q = batch_ptr(p0.Q, p0.bk); p.s = batch_ptr(p0.s, p0.bk);
+    p.C = batch_ptr(p0.C, p0.bk); p.ws = batch_ptr(p0.ws, p0.bk);
+    return p;
+}
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range.
@@ -183,7 +191,9 @@ __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (
 //            (stream-K): the tail that would otherwise leave most CUs idle.  A workgroup's partial
 //            first/last tile goes to a slab; gemm_nt_fixup_kernel adds the slabs in workgroup order.
 template <bool SCALE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p0) {
+    if (batch_done(p0.bk)) return;
+    const GemmK p = batch_shift(p0);
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
     TILE_THREAD_IDS
@@ -247,7 +257,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p) 
 // One full tile per workgroup (Cholesky trailing update, TRSM-as-GEMM): no k-split, no slabs.
 // Tile coordinates are in units of (32*MTM rows, 32*MTN columns).
 template <int MTM, int MTN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(const GemmK p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(const GemmK p0) {
+    if (batch_done(p0.bk)) return;
+    const GemmK p = batch_shift(p0);
     constexpr int TM = 32 * MTM, TN = 32 * MTN;
     __shared__ __attribute__((aligned(16))) double ldsA[2][TM][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TN][LDS_STRIDE];
@@ -271,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(const GemmK p) {
 // prefetch of tile_mainloop cannot hide a global-load round trip, so all 8 k-tiles are requested up
 // front (they fit in registers for these small tiles) and the round trip is paid once per tile.
 template <int MTM, int MTN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_tile_k128_kernel(const GemmK p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_k128_kernel(const GemmK p0) {
+    if (batch_done(p0.bk)) return;
+    const GemmK p = batch_shift(p0);
     constexpr int TM = 32 * MTM, TN = 32 * MTN, KT8 = 8;
     __shared__ __attribute__((aligned(16))) double ldsA[2][TM][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TN][LDS_STRIDE];
@@ -325,11 +339,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_k128_kernel(const GemmK p
 
 // Grouped GEMM: every workgroup takes its own descriptor (operands, k-range, alpha): the doubling
 // levels of the super-block triangular inverse are a few such launches over many small products.
-__global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileDesc* __restrict__ descs, BatchK bk) {
+    if (batch_done(bk)) return;
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
     TILE_THREAD_IDS
-    const GemmTileDesc d = descs[blockIdx.x];
+    GemmTileDesc d = descs[blockIdx.x];
+    d.P = batch_ptr(d.P, bk); d.Q = batch_ptr(d.Q, bk); d.C = batch_ptr(d.C, bk);
     d4 acc[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -345,7 +361,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileD
 // order.  grid = remainder tiles x FIX_SPLIT: a tile can have dozens of slabs, so its 16K elements are
 // spread over FIX_SPLIT workgroups (8 rows each) to keep this pass off the critical path.
 constexpr int FIX_SPLIT = 16;
-__global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p) {
+__global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
+    if (batch_done(p0.bk)) return;
+    const GemmK p = batch_shift(p0);
     const int KT = p.KT;
     const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
     const int rt = blockIdx.x / FIX_SPLIT, chunk = blockIdx.x % FIX_SPLIT;
@@ -388,18 +406,19 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.P = a.P; k.ldp = a.ldp; k.Q = a.Q; k.ldq = a.ldq; k.s = a.s;
     k.C = a.C; k.ldc = a.ldc; k.KT = a.K / BK; k.alpha = a.alpha; k.beta = a.beta;
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
-    k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg;
+    k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg; k.bk = batch_k(a.batch);
+    const int B = a.batch.count;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
     if (a.nwg == a.ntiles && !a.s && a.diag_pad_from < 0) {   // one whole tile per workgroup
-        if (a.tile_edge == 64 && k.KT == 8)      hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
-        else if (a.tile_edge == 32 && k.KT == 8) hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<1, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
-        else if (a.tile_edge == 64) hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles), dim3(256), 0, st, k);
-        else if (a.tile_edge == 32) hipLaunchKernelGGL((gemm_nt_tile_kernel<1, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
-        else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles), dim3(256), 0, st, k);
+        if (a.tile_edge == 64 && k.KT == 8)      hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<2, 2>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
+        else if (a.tile_edge == 32 && k.KT == 8) hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<1, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
+        else if (a.tile_edge == 64) hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
+        else if (a.tile_edge == 32) hipLaunchKernelGGL((gemm_nt_tile_kernel<1, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
+        else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         return hipGetLastError();
     }
-    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, dim3(a.nwg), dim3(256), 0, st, k);
-    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, dim3(a.nwg), dim3(256), 0, st, k);
+    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, dim3(a.nwg, 1, B), dim3(256), 0, st, k);
+    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, dim3(a.nwg, 1, B), dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // remainder tiles: a split exists unless every workgroup boundary falls on a tile boundary
@@ -408,15 +427,15 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     bool split = false;
     for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
     if (split) {
-        hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(nrem * FIX_SPLIT), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(nrem * FIX_SPLIT, 1, B), dim3(256), 0, st, k);
         e = hipGetLastError();
     }
     return e;
 }
 
-hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st) {
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles), dim3(256), 0, st, descs_dev);
+    hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
     return hipGetLastError();
 }
 

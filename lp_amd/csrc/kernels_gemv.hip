@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
                                                      int np, const double* __restrict__ W, long long ldw,
                                                      const double* add0,
                                                      const double* add1,
-                                                     double* Y, long long ldy, double alpha) {
+                                                     double* Y, long long ldy, double alpha, BatchK bk) {
+    if (batch_done(bk)) return;
+    A = batch_ptr(A, bk); W = batch_ptr(W, bk); add0 = batch_ptr(add0, bk); add1 = batch_ptr(add1, bk);
+    Y = batch_ptr(Y, bk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * GN_ROWS_PER_WG + wave * GN_ROWS_PER_WAVE;
     if (row0 >= m) return;
@@ -72,7 +75,9 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
 template <int NRHS>
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, long long lda, int np,
                                                      const double* __restrict__ V, long long ldv,
-                                                     double* __restrict__ Upart, long long slab) {
+                                                     double* __restrict__ Upart, long long slab, BatchK bk) {
+    if (batch_done(bk)) return;
+    A = batch_ptr(A, bk); V = batch_ptr(V, bk); Upart = batch_ptr(Upart, bk);
     __shared__ double vs[NRHS][GEMVT_ROWS];
     const int tid = threadIdx.x;
     const int col = (blockIdx.x * 256 + tid) * 2;
@@ -110,25 +115,25 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __rest
 
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
-                         hipStream_t st, double alpha) {
-    const int grid = (m + GN_ROWS_PER_WG - 1) / GN_ROWS_PER_WG;
+                         hipStream_t st, double alpha, const Batch& bt) {
+    const dim3 grid((m + GN_ROWS_PER_WG - 1) / GN_ROWS_PER_WG, 1, bt.count);
     if (nrhs == 1)
-        hipLaunchKernelGGL(gemv_n_kernel<1>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha);
+        hipLaunchKernelGGL(gemv_n_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, m, np, W,
+                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha, batch_k(bt));
     else
-        hipLaunchKernelGGL(gemv_n_kernel<2>, dim3(grid), dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha);
+        hipLaunchKernelGGL(gemv_n_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, m, np, W,
+                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha, batch_k(bt));
     return hipGetLastError();
 }
 
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
-                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab) {
+                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab, const Batch& bt) {
     if (slab <= 0) slab = np;
-    dim3 grid((np / 2 + 255) / 256, mp / GEMVT_ROWS);
+    dim3 grid((np / 2 + 255) / 256, mp / GEMVT_ROWS, bt.count);
     if (nrhs == 1)
-        hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab);
+        hipLaunchKernelGGL(gemv_t_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab, batch_k(bt));
     else
-        hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab);
+        hipLaunchKernelGGL(gemv_t_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, np, V, (long long)ldv, Upart, (long long)slab, batch_k(bt));
     return hipGetLastError();
 }
 
@@ -138,40 +143,48 @@ hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs,
 //   A^T.v    : u[nx + i]    = v[i]               (goes to row-split slab 0; the other slabs hold 0 there)
 //   A.D.A^T  : M[i][i]     += d[nx + i]
 __global__ __launch_bounds__(256) void slack_n_kernel(int ns, int nx, int nrhs, const double* __restrict__ W,
-                                                      long long ldw, double* __restrict__ Y, long long ldy) {
+                                                      long long ldw, double* __restrict__ Y, long long ldy, BatchK bk) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns) return;
+    if (i >= ns || batch_done(bk)) return;
+    W = batch_ptr(W, bk); Y = batch_ptr(Y, bk);
     for (int q = 0; q < nrhs; ++q) Y[q * ldy + i] += W[q * ldw + nx + i];
 }
 // grid.y = row splits: split 0 receives v, every other split an explicit 0 (the slab buffer is shared by
 // the 1- and 2-vector layouts, so "never written" is not the same as zero)
 __global__ __launch_bounds__(256) void slack_t_kernel(int ns, int nx, int nrhs, const double* __restrict__ V,
-                                                      long long ldv, double* __restrict__ Upart, long long slab) {
+                                                      long long ldv, double* __restrict__ Upart, long long slab, BatchK bk) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns) return;
+    if (i >= ns || batch_done(bk)) return;
+    V = batch_ptr(V, bk); Upart = batch_ptr(Upart, bk);
     const int sp = blockIdx.y;
     for (int q = 0; q < nrhs; ++q)
         Upart[((long long)sp * nrhs + q) * slab + nx + i] = sp == 0 ? V[q * ldv + i] : 0.0;
 }
 __global__ __launch_bounds__(256) void slack_diag_kernel(int ns, int nx, const double* __restrict__ d,
-                                                         double* __restrict__ M, long long ldm) {
+                                                         double* __restrict__ M, long long ldm, BatchK bk) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns) return;
+    if (i >= ns || batch_done(bk)) return;
+    d = batch_ptr(d, bk); M = batch_ptr(M, bk);
     M[(long long)i * ldm + i] += d[nx + i];
 }
-hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st) {
+hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st,
+                          const Batch& bt) {
     if (ns <= 0) return hipSuccess;
-    hipLaunchKernelGGL(slack_n_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, nx, nrhs, W, (long long)ldw, Y, (long long)ldy);
+    hipLaunchKernelGGL(slack_n_kernel, dim3((ns + 255) / 256, 1, bt.count), dim3(256), 0, st, ns, nx, nrhs, W, (long long)ldw, Y,
+                       (long long)ldy, batch_k(bt));
     return hipGetLastError();
 }
-hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab, hipStream_t st) {
+hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab,
+                          hipStream_t st, const Batch& bt) {
     if (ns <= 0) return hipSuccess;
-    hipLaunchKernelGGL(slack_t_kernel, dim3((ns + 255) / 256, nsplit), dim3(256), 0, st, ns, nx, nrhs, V, (long long)ldv, Upart, (long long)slab);
+    hipLaunchKernelGGL(slack_t_kernel, dim3((ns + 255) / 256, nsplit, bt.count), dim3(256), 0, st, ns, nx, nrhs, V, (long long)ldv,
+                       Upart, (long long)slab, batch_k(bt));
     return hipGetLastError();
 }
-hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st) {
+hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st, const Batch& bt) {
     if (ns <= 0) return hipSuccess;
-    hipLaunchKernelGGL(slack_diag_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, ns, nx, d, M, (long long)ldm);
+    hipLaunchKernelGGL(slack_diag_kernel, dim3((ns + 255) / 256, 1, bt.count), dim3(256), 0, st, ns, nx, d, M, (long long)ldm,
+                       batch_k(bt));
     return hipGetLastError();
 }
 

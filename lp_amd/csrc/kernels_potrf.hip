@@ -279,7 +279,9 @@ __device__ __forceinline__ void update_tiles(double (*Ls)[LS], const double (*xi
 __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mblk, long long ld,
                                                         double* __restrict__ Linv, double* __restrict__ LinvT,
                                                         long long ldinv, int32_t* info, int global_row0,
-                                                        long long* stamps) {
+                                                        long long* stamps, BatchK bk) {
+    if (batch_done(bk)) return;
+    Mblk = batch_ptr(Mblk, bk); Linv = batch_ptr(Linv, bk); LinvT = batch_ptr(LinvT, bk); info = batch_ptr(info, bk);
 #define STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = clock64(); } while (0)
     __shared__ __attribute__((aligned(16))) double Ls[NB][LS];            // 133,120 B
     __shared__ __attribute__((aligned(16))) double xid[2][SB][XS];        // eliminated NEW identity rows (double-buffered)
@@ -359,8 +361,11 @@ long long* g_diag_stamps = nullptr;  // debug: device buffer of 8 cycle stamps f
 // passes over the trailing matrix (at K = 128 that update is bound by the C-tile traffic, 16 flop/B).
 constexpr int OUTER = 4;
 
-hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t), st);
+hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
+                        const Batch& bt) {
+    // (a finished LP of a batch has its info word cleared too: its status record already holds the value)
+    hipError_t e = bt.count == 1 ? hipMemsetAsync(info, 0, sizeof(int32_t), st)
+                                 : hipMemset2DAsync(info, (size_t)bt.stride, 0, sizeof(int32_t), (size_t)bt.count, st);
     if (e != hipSuccess) return e;
     const int nb = mp / NB;
     for (int J0 = 0; J0 < nb; J0 += OUTER) {
@@ -370,9 +375,9 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
             double* diag = M + o * ld + o;
             double* linv = plan.blk_inv(j);
             const int ldinv = plan.blk_ld(j);
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DT), 0, st, diag, (long long)ld, linv,
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, bt.count), dim3(DT), 0, st, diag, (long long)ld, linv,
                                plan.blk_invT(j), (long long)ldinv, info, (int)o,
-                               (long long*)(j == 0 ? g_diag_stamps : nullptr));
+                               (long long*)(j == 0 ? g_diag_stamps : nullptr), batch_k(bt));
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             const int rem = nb - j - 1;
@@ -385,7 +390,7 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
             // workgroup still owns whole rows, so the product may overwrite its own input
             t.tile_edge = 32;
             t.ntiles = 4 * rem; t.tiles_lower = 0; t.ntj = 1; t.tile_list = nullptr;
-            t.diag_pad_from = -1; t.ws = nullptr; t.nwg = t.ntiles;
+            t.diag_pad_from = -1; t.ws = nullptr; t.nwg = t.ntiles; t.batch = bt;
             e = launch_gemm_nt(t, st);
             if (e != hipSuccess) return e;
             const int ncols = J1 - j - 1;            // column blocks of the outer panel right of j
@@ -396,7 +401,7 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
                 c.P = panel; c.ldp = ld; c.Q = panel; c.ldq = ld; c.s = nullptr;
                 c.C = M + (o + NB) * ld + (o + NB); c.ldc = ld; c.K = NB; c.alpha = -1.0; c.beta = 1.0;
                 c.tile_edge = 64; c.tiles_lower = 0; c.ntj = 2 * ncols; c.ntiles = (2 * rem) * (2 * ncols);
-                c.tile_list = nullptr; c.diag_pad_from = -1; c.ws = nullptr; c.nwg = c.ntiles;
+                c.tile_list = nullptr; c.diag_pad_from = -1; c.ws = nullptr; c.nwg = c.ntiles; c.batch = bt;
                 e = launch_gemm_nt(c, st);
                 if (e != hipSuccess) return e;
             }
@@ -410,7 +415,7 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
             u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
             if (remT * (remT + 1) / 2 < 128) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
             else                             { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
-            u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles;
+            u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles; u.batch = bt;
             e = launch_gemm_nt(u, st);
             if (e != hipSuccess) return e;
         }
@@ -418,7 +423,7 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
     // inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
     // grouped launch of stage A (T^T = Inv11^T.L21^T) then stage B (Inv21 = -Inv22.T and its transpose)
     for (const auto& stg : plan.stages) {
-        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st);
+        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st, bt);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -54,22 +54,17 @@ int plan_merges(int sb, int lo, int hi, std::vector<Merge>& out, size_t& tcursor
 }
 }  // namespace
 
-hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, hipStream_t st) {
+hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build,
+                              hipStream_t st) {
     factor_plan_destroy(plan);
     plan.mp = mp;
     hipError_t e;
-    auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
-        hipError_t er = hipMalloc(p, bytes ? bytes : 8);
-        if (er != hipSuccess) return er;
-        plan.allocs.push_back(*p);
-        return hipMemsetAsync(*p, 0, bytes ? bytes : 8, st);
-    };
     for (int r0 = 0; r0 < mp; r0 += SUPER) {
         SuperBlock s{};
         s.row0 = r0;
         s.size = mp - r0 < SUPER ? mp - r0 : SUPER;
-        if ((e = dalloc((void**)&s.inv, (size_t)s.size * s.size * sizeof(double))) != hipSuccess) return e;
-        if ((e = dalloc((void**)&s.invT, (size_t)s.size * s.size * sizeof(double))) != hipSuccess) return e;
+        s.inv = arena.take<double>((size_t)s.size * s.size);
+        s.invT = arena.take<double>((size_t)s.size * s.size);
         plan.sbs.push_back(s);
     }
     std::vector<Merge> merges;
@@ -79,11 +74,10 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
         const int lvl = plan_merges((int)i, 0, plan.sbs[i].size / NB, merges, tcursor);
         if (lvl > maxlvl) maxlvl = lvl;
     }
-    double* tws = nullptr;
-    if ((e = dalloc((void**)&tws, tcursor * sizeof(double))) != hipSuccess) return e;
+    double* tws = arena.take<double>(tcursor);
     // slabs of the backward sweep's transposed panel products: (rows below / 128) x 2 rhs x SUPER
-    if ((e = dalloc((void**)&plan.tpart, (size_t)(mp / GEMVT_ROWS + 1) * 2 * SUPER * sizeof(double))) != hipSuccess)
-        return e;
+    plan.tpart = arena.take<double>((size_t)(mp / GEMVT_ROWS + 1) * 2 * SUPER);
+    if (!build) return hipSuccess;
 
     std::vector<GemmTileDesc> descs;
     plan.stages.clear();
@@ -147,7 +141,7 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
         }
         plan.stages.push_back({b0, (int)descs.size() - b0});
     }
-    if ((e = dalloc((void**)&plan.descs_dev, descs.size() * sizeof(GemmTileDesc))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&plan.descs_dev, (descs.size() + 1) * sizeof(GemmTileDesc))) != hipSuccess) return e;
     if (!descs.empty()) {
         e = hipMemcpyAsync(plan.descs_dev, descs.data(), descs.size() * sizeof(GemmTileDesc), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return e;
@@ -156,8 +150,7 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
 }
 
 void factor_plan_destroy(FactorPlan& plan) {
-    for (void* p : plan.allocs) (void)hipFree(p);
-    plan.allocs.clear();
+    if (plan.descs_dev) (void)hipFree(plan.descs_dev);   // the inverse storage belongs to the arena
     plan.sbs.clear();
     plan.stages.clear();
     plan.descs_dev = nullptr;
@@ -170,9 +163,10 @@ void factor_plan_destroy(FactorPlan& plan) {
 // product into the right-hand side of the backward step, in slab order.
 __global__ __launch_bounds__(256) void trsv_fold_kernel(double* __restrict__ y, long long ldy,
                                                         const double* __restrict__ part, int nsplit, int nrhs,
-                                                        int width) {
+                                                        int width, BatchK bk) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
+    if (c >= width || batch_done(bk)) return;
+    y = batch_ptr(y, bk); part = batch_ptr(part, bk);
     for (int q = 0; q < nrhs; ++q) {
         double s = 0.0;
         for (int sp = 0; sp < nsplit; ++sp) s += part[((long long)sp * nrhs + q) * width + c];
@@ -181,20 +175,20 @@ __global__ __launch_bounds__(256) void trsv_fold_kernel(double* __restrict__ y, 
 }
 
 hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan, int nrhs, double* R,
-                             double* Y, hipStream_t st) {
+                             double* Y, hipStream_t st, const Batch& bt) {
     const int mp = plan.mp;
     hipError_t e;
     const int nsb = (int)plan.sbs.size();
     // forward: L y = r
     for (int k = 0; k < nsb; ++k) {
         const SuperBlock& s = plan.sbs[k];
-        e = launch_gemv_n(s.inv, s.size, s.size, s.size, nrhs, R + s.row0, mp, nullptr, nullptr, Y + s.row0, mp, st);
+        e = launch_gemv_n(s.inv, s.size, s.size, s.size, nrhs, R + s.row0, mp, nullptr, nullptr, Y + s.row0, mp, st, 1.0, bt);
         if (e != hipSuccess) return e;
         const int below = mp - (s.row0 + s.size);
         if (below > 0) {
             double* rb = R + s.row0 + s.size;
             e = launch_gemv_n(L + (size_t)(s.row0 + s.size) * ld + s.row0, ld, below, s.size, nrhs, Y + s.row0, mp, rb,
-                              rb + mp, rb, mp, st, -1.0);
+                              rb + mp, rb, mp, st, -1.0, bt);
             if (e != hipSuccess) return e;
         }
     }
@@ -204,13 +198,13 @@ hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan
         const int below = mp - (s.row0 + s.size);
         if (below > 0) {
             e = launch_gemv_t(L + (size_t)(s.row0 + s.size) * ld + s.row0, ld, below, s.size, nrhs,
-                              R + s.row0 + s.size, mp, plan.tpart, st);
+                              R + s.row0 + s.size, mp, plan.tpart, st, 0, bt);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(trsv_fold_kernel, dim3((s.size + 255) / 256), dim3(256), 0, st, Y + s.row0,
-                               (long long)mp, plan.tpart, below / GEMVT_ROWS, nrhs, s.size);
+            hipLaunchKernelGGL(trsv_fold_kernel, dim3((s.size + 255) / 256, 1, bt.count), dim3(256), 0, st, Y + s.row0,
+                               (long long)mp, plan.tpart, below / GEMVT_ROWS, nrhs, s.size, batch_k(bt));
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        e = launch_gemv_n(s.invT, s.size, s.size, s.size, nrhs, Y + s.row0, mp, nullptr, nullptr, R + s.row0, mp, st);
+        e = launch_gemv_n(s.invT, s.size, s.size, s.size, nrhs, Y + s.row0, mp, nullptr, nullptr, R + s.row0, mp, st, 1.0, bt);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

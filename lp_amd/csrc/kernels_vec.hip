@@ -53,6 +53,23 @@ __device__ __forceinline__ double fold_min(const double* red, int slot, int nblk
     return wave_min(s);
 }
 
+// LP blockIdx.z of a lockstep batch.  `check_done`: kernels of the iteration skip an LP that has finished.
+__device__ __forceinline__ bool vbatch(VecArgs& a, bool check_done) {
+    const BatchK bk{a.bstride, check_done ? a.done : nullptr};
+    if (batch_done(bk)) return false;
+    if (blockIdx.z == 0) return true;
+    a.b = batch_ptr(a.b, bk); a.c = batch_ptr(a.c, bk);
+    a.x = batch_ptr(a.x, bk); a.y = batch_ptr(a.y, bk); a.z = batch_ptr(a.z, bk);
+    a.dinv = batch_ptr(a.dinv, bk); a.xs = batch_ptr(a.xs, bk); a.r1 = batch_ptr(a.r1, bk); a.rD = batch_ptr(a.rD, bk);
+    a.p = batch_ptr(a.p, bk); a.u = batch_ptr(a.u, bk); a.dx = batch_ptr(a.dx, bk); a.dz = batch_ptr(a.dz, bk);
+    a.dxdz = batch_ptr(a.dxdz, bk);
+    a.rP = batch_ptr(a.rP, bk); a.rP2 = batch_ptr(a.rP2, bk); a.q = batch_ptr(a.q, bk); a.dy = batch_ptr(a.dy, bk);
+    a.Ax = batch_ptr(a.Ax, bk); a.W = batch_ptr(a.W, bk); a.R = batch_ptr(a.R, bk); a.ATpart = batch_ptr(a.ATpart, bk);
+    a.S = batch_ptr(a.S, bk); a.red = batch_ptr(a.red, bk); a.status = batch_ptr(a.status, bk);
+    a.potrf_info = batch_ptr(a.potrf_info, bk); a.flags = batch_ptr(a.flags, bk); a.done = batch_ptr(a.done, bk);
+    return true;
+}
+
 // n-split mode: gs[first .. first+count) <- fold of the reduction slots (sum or min), optionally the NaN
 // flag as a number in gs[flag_slot]; the host then reduces gs across ranks.
 __global__ void k_fold(VecArgs a, int first, int count, int is_min, int flag_slot) {
@@ -85,6 +102,7 @@ __global__ __launch_bounds__(256) void k_pack_lower(double* __restrict__ M, long
 // ---------------------------------------------------------------- FeasiblePoint::blind_start
 // feasible_point.rs:24-31: x = 1, y = 0, z = 1, tau = kappa = 1
 __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
+    if (!vbatch(a, false)) return;
     const int stride = gridDim.x * 256;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) { a.x[j] = 1.0; a.z[j] = 1.0; }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.y[i] = 0.0;
@@ -92,6 +110,7 @@ __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
         a.S[S_TAU] = 1.0;
         a.S[S_KAPPA] = 1.0;
         *a.flags = 0;
+        *a.done = 0;
     }
 }
 
@@ -101,6 +120,7 @@ __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
 //   r_D = c*tau - A^T.y - z      (A^T.y = sum of the gemv_t row-split slabs)
 // partial sums: |r_P|^2, b.y, |r_D|^2, c.x, x.z, c.(x/tau)   (indicators.rs:41-44)
 __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     const double tau = a.S[S_TAU];
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -127,7 +147,8 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
 // Residuals::calculate + Indicators::from_point_and_problem + Indicators::status
 // (residual.rs:33-43, indicators.rs:37-55, :57-83), then the scalars the NEXT get_delta starts
 // from (feasible_point.rs:119-125, rhat.rs:31,33).
-__global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol, double c0) {
+__global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol) {
+    if (!vbatch(a, true)) return;
     const int nblk = a.nblk;
     // |r_P|^2 and b.y run over m (replicated on every rank); the other four over the (possibly split) n
     const double rp2 = fold_sum(a.red, 0, nblk), by = fold_sum(a.red, 1, nblk);
@@ -144,7 +165,7 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
         S[S_RP0] = rho_p; S[S_RD0] = rho_d; S[S_RG0] = rho_g; S[S_RMU0] = rho_mu;
     }
     StatusRec* st = a.status;
-    const double obj = cxt + c0;                                      // indicators.rs:41
+    const double obj = cxt + S[S_C0];                                 // indicators.rs:41
     const double bty = by;                                            // indicators.rs:42
     const double rho_A = fabs(cx - bty) / (tau + fabs(by));           // indicators.rs:43-44
     const double ip_ = rho_p / fmax(S[S_RP0], 1.0);                   // indicators.rs:47
@@ -165,6 +186,8 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
     st->status = status;
     st->potrf_info = *a.potrf_info;
     st->flags = *a.flags;
+    // what ends the loop of solve_normal_form (mod.rs:215, :231-233): from here on the LP's kernels are skipped
+    if (!is_init && (status != ST_UNFINISHED || *a.potrf_info != 0 || (*a.flags & FLAG_NAN_PQ))) *a.done = 1;
     // next get_delta (feasible_point.rs:119-125)
     const double gamma = ip_next ? 1.0 : 0.0;
     const double eta = ip_next ? 1.0 : 1.0 - gamma;
@@ -180,6 +203,7 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
 // second sym_solve (newton_equations.rs:188: rhat.d - rhat.xs/x) and the Dinv*r1 prologues of both
 // sym_solve calls (:220).
 __global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     const double gm = a.S[S_GAMMA] * a.S[S_MU], eta = a.S[S_ETA];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
 // sym_solve epilogue u = Dinv*(A^T.v - r1) for both solves of the predictor
 // (newton_equations.rs:223), the four dots of delta.rs:29-32 and the NaN check of :190-194.
 __global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     double acc[4] = {0, 0, 0, 0};
     int nan = 0;
@@ -230,6 +255,7 @@ __global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
 // corrector: only (u, v) change; (p, q) are identical to the predictor's (the reference recomputes
 // them, feasible_point.rs:149 -> newton_equations.rs:187, with the same inputs and factor).
 __global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     double acc[2] = {0, 0};
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
@@ -246,6 +272,7 @@ __global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
 // delta.rs:29-32 (d_tau) and :38 (d_kappa).  phase 0: predictor (all four dots fresh);
 // phase 1: corrector (c.p, b.q reused from the predictor).
 __global__ void k_scalar_dtau(VecArgs a, int phase) {
+    if (!vbatch(a, true)) return;
     const int nblk = a.nblk;
     double cp, cu, bq, bv;
     if (phase == 0) {   // c.p, c.u run over the (possibly split) n; b.q, b.v over m (replicated)
@@ -269,6 +296,7 @@ __global__ void k_scalar_dtau(VecArgs a, int phase) {
 // delta.rs:33-37 + the folds of get_step_size (feasible_point.rs:54-62).
 // phase 0 keeps only d_x*d_z (all the corrector needs, rhat.rs:55,64); phase 1 keeps d_x, d_y, d_z.
 __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     const double d_tau = a.S[S_DTAU];
     double mn[2] = {1.0, 1.0};
@@ -291,6 +319,7 @@ __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
 // update_gamma (:156-165), eta (:136) and the scalar parts of Rhat::corrector (rhat.rs:51-74).
 // phase 1: the step length of the iteration (interior_point/mod.rs:216-221).
 __global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
+    if (!vbatch(a, true)) return;
     const int nblk = a.nblk;
     const double ax = a.gs ? a.gs[0] : fold_min(a.red, 0, nblk, 1.0), az = a.gs ? a.gs[1] : fold_min(a.red, 1, nblk, 1.0);
     if (threadIdx.x != 0) return;
@@ -324,6 +353,7 @@ __global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
 // Rhat::corrector vector parts (rhat.rs:51-56 / :62-64, :69-70) and the r1 / Dinv*r1 of the
 // corrector's sym_solve (newton_equations.rs:188, :220).
 __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     const double gamma = a.S[S_GAMMA], mu = a.S[S_MU], eta = a.S[S_ETA], alpha = a.S[S_ALPHA_PRED];
     const double alpha_2 = alpha * alpha;
@@ -344,6 +374,7 @@ __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
 
 // FeasiblePoint::do_step (feasible_point.rs:76-106)
 __global__ __launch_bounds__(256) void k_step(VecArgs a, int ip) {
+    if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
     const double alpha = a.S[S_ALPHA];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
@@ -357,6 +388,7 @@ __global__ __launch_bounds__(256) void k_step(VecArgs a, int ip) {
 }
 // tau / kappa part of do_step: separate one-thread launch so that no kernel both reads and writes S
 __global__ void k_step_scalars(VecArgs a, int ip) {
+    if (!vbatch(a, true)) return;
     if (threadIdx.x != 0) return;
     double* S = a.S;
     const double alpha = S[S_ALPHA];
@@ -369,6 +401,8 @@ __global__ void k_step_scalars(VecArgs a, int ip) {
 
 // x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
 __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
+    if (!vbatch(a, false)) return;
+    xout = batch_ptr(xout, BatchK{a.bstride, nullptr});
     const int stride = gridDim.x * 256;
     const double tau = a.S[S_TAU];
     double acc[1] = {0};
@@ -379,13 +413,15 @@ __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
     }
     block_reduce_store<1, false>(acc, a.red, 0);
 }
-__global__ void k_scalar_fun(VecArgs a, double c0) {
+__global__ void k_scalar_fun(VecArgs a) {
+    if (!vbatch(a, false)) return;
     const double s = a.gs ? a.gs[0] : fold_sum(a.red, 0, a.nblk);
-    if (threadIdx.x == 0) a.status->obj = s + c0;
+    if (threadIdx.x == 0) a.status->obj = s + a.S[S_C0];
 }
 
 // ---------------------------------------------------------------- launchers
-static inline dim3 vgrid(const VecArgs& a) { return dim3(a.nblk); }
+static inline dim3 vgrid(const VecArgs& a) { return dim3(a.nblk, 1, a.bcount); }
+static inline dim3 sgrid(const VecArgs& a) { return dim3(1, 1, a.bcount); }
 
 void vec_blind_start(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_blind_start, vgrid(a), dim3(256), 0, st, a); }
 static int cross(const VecArgs& a, const XRank* xr, int first, int count, int is_min, int flag_slot, int red_first,
@@ -394,40 +430,40 @@ static int cross(const VecArgs& a, const XRank* xr, int first, int count, int is
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, st, a, first, count, is_min, flag_slot);
     return xr->fn(xr->self, a.gs + red_first, red_count, is_min);
 }
-int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st, const XRank* xr) {
+int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);
     if (int rc = cross(a, xr, 2, 4, 0, -1, 2, 4, st)) return rc;     // |r_D|^2, c.x, x.z, c.(x/tau)
-    hipLaunchKernelGGL(k_scalar_indicators, dim3(1), dim3(64), 0, st, a, is_init, ip_next, tol, c0);
+    hipLaunchKernelGGL(k_scalar_indicators, sgrid(a), dim3(64), 0, st, a, is_init, ip_next, tol);
     return 0;
 }
 void vec_pred_setup(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_pred_setup, vgrid(a), dim3(256), 0, st, a); }
 int vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_pq_uv, vgrid(a), dim3(256), 0, st, a);
     if (int rc = cross(a, xr, 0, 2, 0, 2, 0, 3, st)) return rc;      // c.p, c.u and the NaN-in-p flag (gs[2])
-    hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 0);
+    hipLaunchKernelGGL(k_scalar_dtau, sgrid(a), dim3(64), 0, st, a, 0);
     return 0;
 }
 int vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_uv_corr, vgrid(a), dim3(256), 0, st, a);
     if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.u
-    hipLaunchKernelGGL(k_scalar_dtau, dim3(1), dim3(64), 0, st, a, 1);
+    hipLaunchKernelGGL(k_scalar_dtau, sgrid(a), dim3(64), 0, st, a, 1);
     return 0;
 }
 int vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_delta, vgrid(a), dim3(256), 0, st, a, phase);
     if (int rc = cross(a, xr, 0, 2, 1, -1, 0, 2, st)) return rc;     // ratio-test minima over x and z
-    hipLaunchKernelGGL(k_scalar_alpha, dim3(1), dim3(64), 0, st, a, phase, ip, alpha0);
+    hipLaunchKernelGGL(k_scalar_alpha, sgrid(a), dim3(64), 0, st, a, phase, ip, alpha0);
     return 0;
 }
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) { hipLaunchKernelGGL(k_corr_setup, vgrid(a), dim3(256), 0, st, a, ip); }
 void vec_step(const VecArgs& a, int ip, hipStream_t st) {
     hipLaunchKernelGGL(k_step, vgrid(a), dim3(256), 0, st, a, ip);
-    hipLaunchKernelGGL(k_step_scalars, dim3(1), dim3(64), 0, st, a, ip);
+    hipLaunchKernelGGL(k_step_scalars, sgrid(a), dim3(64), 0, st, a, ip);
 }
-int vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const XRank* xr) {
+int vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_final_x, vgrid(a), dim3(256), 0, st, a, xout);
     if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.(x/tau)
-    hipLaunchKernelGGL(k_scalar_fun, dim3(1), dim3(64), 0, st, a, c0);
+    hipLaunchKernelGGL(k_scalar_fun, sgrid(a), dim3(64), 0, st, a);
     return 0;
 }
 void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st) {

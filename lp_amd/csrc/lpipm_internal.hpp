@@ -28,6 +28,46 @@ void set_error_detail(const char* what, hipError_t e, const char* file, int line
         }                                                                   \
     } while (0)
 
+// ---------------------------------------------------------------- lockstep batches
+// `count` LPs of identical geometry live in identical arenas `stride` BYTES apart and advance in
+// lockstep: every launch covers all of them through gridDim.z, a kernel of LP z shifts each of its
+// pointers by z*stride.  done (nullable) is LP 0's "finished" word: an LP whose word is non-zero is
+// skipped by every kernel, so its iterate stays frozen while the others go on.
+// count == 1, stride == 0 is the ordinary single-LP launch.
+struct Batch {
+    int count = 1;
+    long long stride = 0;
+    const int* done = nullptr;
+};
+struct BatchK { long long stride; const int* done; };   // the part a kernel needs
+inline BatchK batch_k(const Batch& b) { return BatchK{b.stride, b.done}; }
+#ifdef __HIPCC__
+__device__ __forceinline__ bool batch_done(const BatchK& b) {
+    return b.done && *(const int*)((const char*)b.done + (long long)blockIdx.z * b.stride) != 0;
+}
+template <typename T>
+__device__ __forceinline__ T* batch_ptr(T* p, const BatchK& b) {   // null stays null
+    return p ? (T*)((char*)p + (long long)blockIdx.z * b.stride) : p;
+}
+template <typename T>
+__device__ __forceinline__ const T* batch_ptr(const T* p, const BatchK& b) {
+    return p ? (const T*)((const char*)p + (long long)blockIdx.z * b.stride) : p;
+}
+#endif
+
+// Bump allocator over one arena (per-LP state).  A first pass with base == nullptr only measures.
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = (T*)((uintptr_t)base + off);
+        off += (count ? count : 1) * sizeof(T);
+        return p;
+    }
+};
+
 // ---------------------------------------------------------------- NT GEMM (kernels_gemm.hip)
 // C(tile ti,tj) = beta*C + alpha * sum_k P[ti*128+r][k] * s[k] * Q[tj*128+c][k]
 // Row-major operands with K contiguous ("NT"): this one MFMA kernel serves
@@ -49,6 +89,7 @@ struct GemmArgs {
     double*       ws;           // stream-K partial slabs: 2 per workgroup, TILE*TILE doubles each
     int           nwg;          // workgroups launched (== grid); ntiles*KT split evenly
     int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
+    Batch         batch;        // lockstep batch (every pointer above except tile_list is per LP)
 };
 // Launches the main kernel and, when the k-range of a tile is split over workgroups, the
 // deterministic fix-up pass.  ws must hold 2*nwg slabs when nwg != ntiles.
@@ -61,7 +102,8 @@ struct GemmTileDesc {
     int kt_begin, kt_end;
     double alpha;
 };
-hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st);
+// descs_dev holds LP 0's pointers; LP z of a batch shifts P, Q, C by z*stride.
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt = Batch{});
 // Workgroup count the stream-K ADA^T launch wants for ntiles x KT work.
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 
@@ -78,8 +120,7 @@ struct SuperBlock {
 struct FactorPlan {
     int mp = 0;
     std::vector<SuperBlock> sbs;
-    std::vector<void*> allocs;                   // device memory owned by the plan
-    GemmTileDesc* descs_dev = nullptr;           // grouped-GEMM tiles of all merge stages
+    GemmTileDesc* descs_dev = nullptr;           // grouped-GEMM tiles of all merge stages (own allocation, shared by a batch)
     std::vector<std::pair<int, int>> stages;     // (first descriptor, count) per launch, in order
     double* tpart = nullptr;                     // gemv_t slabs of the backward sweep
     // 128-block k of the factorisation -> where its inverse / transposed inverse go, and their ld
@@ -87,20 +128,23 @@ struct FactorPlan {
     double* blk_invT(int k) const;
     int blk_ld(int k) const;
 };
-// Allocates inverse storage for an mp x mp factor living at (L, ld) and builds the descriptors.
-hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, hipStream_t st);
+// Takes the inverse storage for an mp x mp factor living at (L, ld) from the arena (which must be zeroed:
+// the never-written halves of the triangular inverses are read as zeros) and, when `build`, uploads the
+// merge descriptors.  build == false: sizing pass over a measuring arena, nothing is allocated.
+hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build, hipStream_t st);
 void factor_plan_destroy(FactorPlan& plan);
 
 // ---------------------------------------------------------------- Cholesky (kernels_potrf.hip)
 // In-place blocked lower Cholesky of the mp x mp row-major matrix M (mp multiple of NB), followed by
 // the inverses of the diagonal super-blocks (plan).  info (device int32): 0, or 1 + index of the
 // first non-positive pivot.
-hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st);
+hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
+                        const Batch& bt = Batch{});
 
 // ---------------------------------------------------------------- triangular solves (kernels_trsv.hip)
 // R[r] <- L^-T L^-1 R[r], r < nrhs (1|2); R is nrhs x mp (row stride mp); Yscratch: nrhs x mp.
 hipError_t launch_chol_solve(const double* L, int64_t ld, const FactorPlan& plan, int nrhs, double* R,
-                             double* Yscratch, hipStream_t st);
+                             double* Yscratch, hipStream_t st, const Batch& bt = Batch{});
 
 // ---------------------------------------------------------------- QR arms (kernels_qr.hip)
 // EquationSolverType::{Inverse, LeastSquares}: Householder QR of the full mp x mp matrix whose LOWER
@@ -115,16 +159,19 @@ hipError_t launch_qr_solve(const double* M, int64_t ld, int mp, const double* ta
 // Y[r][i] = (add[r] ? add[r][i] : 0) + alpha * sum_k A[i][k] * W[r][k],   i < m, k < np
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
-                         hipStream_t st, double alpha = 1.0);
+                         hipStream_t st, double alpha = 1.0, const Batch& bt = Batch{});
 // Upart[s][r][k] = sum_{i in row split s} A[i][k] * V[r][i];  consumers sum the splits in order.
 constexpr int GEMVT_ROWS = 128;
 // np: columns processed (multiple of 2); slab: stride between slabs (0 = np)
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
-                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab = 0);
+                         int64_t ldv, double* Upart, hipStream_t st, int64_t slab = 0, const Batch& bt = Batch{});
 // slack structure [I; 0] of the last ns columns (never stored), see kernels_gemv.hip
-hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st);
-hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab, hipStream_t st);
-hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st);
+hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st,
+                          const Batch& bt = Batch{});
+hipError_t launch_slack_t(int ns, int nx, int nrhs, int nsplit, const double* V, int64_t ldv, double* Upart, int64_t slab,
+                          hipStream_t st, const Batch& bt = Batch{});
+hipError_t launch_slack_diag(int ns, int nx, const double* d, double* M, int64_t ldm, hipStream_t st,
+                             const Batch& bt = Batch{});
 // U[r][k] = sum_s Upart[s][r][k]   (stand-alone reduce; the solver fuses this into its consumers)
 hipError_t launch_gemv_t_reduce(const double* Upart, int nsplit, int nrhs, int np, double* U,
                                 int64_t ldu, hipStream_t st);

@@ -44,9 +44,11 @@ struct lpipm_ctx {
     uint64_t m = 0, n = 0;
     int mp = 0, np = 0, nblk = 1, nsplit = 1;
     int ns = 0, nx = 0, npa = 0;   // slack columns (not stored), structural columns, their padded count = lda of A
-    double c0 = 0.0;
-    std::vector<void*> allocs;   // problem-sized device buffers
-    std::vector<size_t> alloc_bytes;
+    // per-LP device state lives in one arena; a lockstep batch of B LPs has B of them, bstride bytes apart
+    char* arena = nullptr;
+    size_t arena_bytes = 0, bstride = 0;
+    int B = 1;
+    Batch bt;                    // what the solve path hands to every launcher (count, stride, done flags)
     std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
     // problem + state + work
     FactorPlan plan, kplan;
@@ -55,7 +57,8 @@ struct lpipm_ctx {
     int2* tile_list = nullptr;
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
-    StatusRec* status_host = nullptr;  // pinned
+    StatusRec* status_host = nullptr;  // pinned, status_cap records
+    size_t status_cap = 0;
     // stand-alone potrf/solve buffers
     double *kM = nullptr, *kM0 = nullptr, *kR = nullptr, *kY = nullptr;
     int32_t* kinfo = nullptr;
@@ -72,6 +75,10 @@ struct lpipm_ctx {
     // batch mode: extra contexts (own stream + buffers) driven by host threads, see lpipm_solve_batch
     std::vector<lpipm_ctx*> workers;
     int batch_concurrency = 0;   // 0 = auto
+    // captured iteration (hipGraph): one executable graph per (ip, options) key, valid while the buffers live
+    struct IterGraph { int ip; double alpha0, tol; hipGraphExec_t exec; };
+    std::vector<IterGraph> graphs;
+    int use_graph = -1;          // -1: decide from the environment / size at first use
     // n-split mode (one LP split by columns over ranks; BASELINE config C5): the collective is the caller's
     bool colsplit = false;
     int rank = 0, world = 1;
@@ -81,6 +88,11 @@ struct lpipm_ctx {
     double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
     size_t mpack_count = 0;
 };
+
+static void drop_graphs(lpipm_ctx* c) {
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
 
 // Cross-rank reduction of `count` doubles at a device pointer, ordered after everything enqueued on the
 // ctx's stream so far (the stream is drained first; the callee returns when the result is in place).
@@ -214,6 +226,7 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
         delete c;
         return LPIPM_ERR_HIP;
     }
+    c->status_cap = 1;
     *out = c;
     return LPIPM_OK;
 }
@@ -224,7 +237,9 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     c->workers.clear();
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
-    free_list(c->allocs);
+    drop_graphs(c);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->tile_list) (void)hipFree(c->tile_list);
     free_list(c->kallocs);
     if (c->mpack) (void)hipFree(c->mpack);
     factor_plan_destroy(c->plan);
@@ -255,6 +270,120 @@ static std::vector<int2> adat_tile_order(int nt) {
     return v;
 }
 
+// Per-LP device state: one pass over a measuring arena sizes it, a second pass over the real one places it.
+// Every LP of a lockstep batch gets the same layout, `bstride` bytes after the previous LP's.
+static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
+    VecArgs& v = c->va;
+    const size_t mp = (size_t)c->mp, np = (size_t)c->np;
+    c->A = ar.take<double>(mp * c->npa);
+    v.b = ar.take<double>(mp); v.c = ar.take<double>(np);
+    v.x = ar.take<double>(np); v.y = ar.take<double>(mp); v.z = ar.take<double>(np);
+    v.dinv = ar.take<double>(np); v.xs = ar.take<double>(np); v.r1 = ar.take<double>(np); v.rD = ar.take<double>(np);
+    v.p = ar.take<double>(np); v.u = ar.take<double>(np); v.dx = ar.take<double>(np); v.dz = ar.take<double>(np);
+    v.dxdz = ar.take<double>(np);
+    v.rP = ar.take<double>(mp); v.rP2 = ar.take<double>(mp); v.q = ar.take<double>(mp); v.dy = ar.take<double>(mp);
+    v.Ax = ar.take<double>(mp);
+    v.W = ar.take<double>(2 * np); v.R = ar.take<double>(2 * mp);
+    c->Y = ar.take<double>(2 * mp);
+    c->ATpart = ar.take<double>((size_t)c->nsplit * 2 * np);
+    v.ATpart = c->ATpart;
+    v.S = ar.take<double>(64); v.red = ar.take<double>((size_t)RED_SLOTS * RED_STRIDE);
+    v.status = ar.take<StatusRec>(1);
+    v.potrf_info = ar.take<int32_t>(1); v.flags = ar.take<int>(1); v.done = ar.take<int>(1);
+    c->M = ar.take<double>(mp * mp);
+    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st));
+    c->tau = ar.take<double>(mp);
+    c->gs = ar.take<double>(8);
+    c->xout = ar.take<double>(np);
+    // stream-K slabs of A.D.A^T: only when a tile's k-range can be split over workgroups
+    c->ws = ar.take<double>(c->adat_nwg == c->ntiles ? 1 : (size_t)2 * c->adat_nwg * TILE * TILE);
+    return LPIPM_OK;
+}
+
+// count LPs of one geometry (count == 1: the ordinary upload).  A/b/cc/c0: one entry per LP.
+static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const double* const* A, uint64_t lda,
+                       const double* const* b, const double* const* cc, const double* c0, uint64_t n_slack) {
+    if (!c || count < 1 || !A || !b || !cc || lda < n) return LPIPM_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < count; ++i)
+        if (!A[i] || !b[i] || !cc[i]) return LPIPM_ERR_BAD_ARGUMENT;
+    if (m == 0) return LPIPM_UNCONSTRAINED;  // linear_program.rs:134-136
+    if (n == 0 || m > (1u << 20) || n > (1u << 24) || n_slack > n || n_slack > m) return LPIPM_ERR_BAD_ARGUMENT;
+    // The hint is only used if the last n_slack columns really are [I; 0] (ProblemBuilder::build
+    // guarantees it, linear_program.rs:147-156); anything else is treated as a dense matrix.
+    if (n_slack == n || count > 1) n_slack = 0;
+    for (uint64_t i = 0; i < m && n_slack; ++i) {
+        const double* row = A[0] + i * lda + (n - n_slack);
+        for (uint64_t j = 0; j < n_slack; ++j)
+            if (row[j] != ((i == j) ? 1.0 : 0.0)) { n_slack = 0; break; }
+    }
+    LP_HIP(hipSetDevice(c->device));
+    drop_graphs(c);   // kernel arguments depend on m, n, n_slack and the buffers
+    const uint64_t nx = n - n_slack;
+    const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK), npa = (int)round_up(nx, BK);
+    hipStream_t st = c->st;
+    if (!c->has_problem || mp != c->mp || np != c->np || npa != c->npa || count != c->B) {
+        LP_HIP(hipStreamSynchronize(st));
+        if (c->arena) { LP_HIP(hipFree(c->arena)); c->arena = nullptr; }
+        if (c->tile_list) { LP_HIP(hipFree(c->tile_list)); c->tile_list = nullptr; }
+        factor_plan_destroy(c->plan);
+        c->has_problem = false;
+        c->mp = mp; c->np = np; c->npa = npa; c->B = count;
+        c->nsplit = mp / GEMVT_ROWS;
+        const uint64_t big = m > n ? m : n;
+        c->nblk = (int)((big + 255) / 256);
+        if (c->nblk > RED_STRIDE) c->nblk = RED_STRIDE;
+        const int nt = mp / TILE;
+        std::vector<int2> order = adat_tile_order(nt);
+        c->ntiles = (int)order.size();
+        // workgroups per LP of the A.D.A^T launch: stream-K over the chip's share of one LP; a batch that
+        // fills the chip with whole tiles needs no k-split (and no slabs)
+        c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, count == 1 ? c->num_cu : c->num_cu / count);
+        if (count > 1 && c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
+        Arena measure;
+        LP_TRY(layout_problem(c, measure, false));
+        c->bstride = round_up(measure.off, 4096);
+        c->arena_bytes = c->bstride * (size_t)count;
+        LP_HIP(hipMalloc((void**)&c->arena, c->arena_bytes));
+        LP_HIP(hipMemsetAsync(c->arena, 0, c->arena_bytes, st));
+        Arena real;
+        real.base = c->arena;
+        LP_TRY(layout_problem(c, real, true));
+        LP_HIP(hipMalloc((void**)&c->tile_list, order.size() * sizeof(int2)));
+        LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        LP_HIP(hipStreamSynchronize(st));  // `order` must outlive the copy
+        if ((size_t)count > c->status_cap) {
+            if (c->status_host) (void)hipHostFree(c->status_host);
+            c->status_host = nullptr; c->status_cap = 0;
+            LP_HIP(hipHostMalloc((void**)&c->status_host, (size_t)count * sizeof(StatusRec)));
+            c->status_cap = (size_t)count;
+        }
+        VecArgs& v = c->va;
+        v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
+        v.bcount = count; v.bstride = (long long)c->bstride;
+    } else {
+        // same padded geometry: clear the whole state, so no stale (possibly non-finite) value of a
+        // previous problem can sit in a padding lane
+        LP_HIP(hipMemsetAsync(c->arena, 0, c->arena_bytes, st));
+    }
+    c->m = m; c->n = n;
+    c->ns = (int)n_slack; c->nx = (int)nx;
+    c->va.n = (int)n; c->va.m = (int)m;
+    c->va.n_total = (long long)n; c->va.gs = nullptr; c->colsplit = false;   // lpipm_upload_nsplit overrides
+    c->bt = Batch{count, (long long)c->bstride, c->va.done};
+    for (int i = 0; i < count; ++i) {
+        const size_t off = (size_t)i * c->bstride;
+        LP_HIP(hipMemcpy2DAsync((char*)c->A + off, (size_t)npa * sizeof(double), A[i], (size_t)lda * sizeof(double),
+                                (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, st));
+        LP_HIP(hipMemcpyAsync((char*)c->va.b + off, b[i], m * sizeof(double), hipMemcpyHostToDevice, st));
+        LP_HIP(hipMemcpyAsync((char*)c->va.c + off, cc[i], n * sizeof(double), hipMemcpyHostToDevice, st));
+        const double c0i = c0 ? c0[i] : 0.0;
+        LP_HIP(hipMemcpyAsync((char*)(c->va.S + S_C0) + off, &c0i, sizeof(double), hipMemcpyHostToDevice, st));
+        LP_HIP(hipStreamSynchronize(st));   // c0i lives on this stack frame; pageable sources are staged anyway
+    }
+    c->has_problem = true;
+    return LPIPM_OK;
+}
+
 extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                             const double* b, const double* cc, double c0) {
     return lpipm_upload_slack(c, m, n, A, lda, b, cc, c0, 0);
@@ -262,121 +391,54 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
 
 extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                                   const double* b, const double* cc, double c0, uint64_t n_slack) {
-    if (!c || !A || !b || !cc || lda < n) return LPIPM_ERR_BAD_ARGUMENT;
-    if (m == 0) return LPIPM_UNCONSTRAINED;  // linear_program.rs:134-136
-    if (n == 0 || m > (1u << 20) || n > (1u << 24) || n_slack > n || n_slack > m) return LPIPM_ERR_BAD_ARGUMENT;
-    // The hint is only used if the last n_slack columns really are [I; 0] (ProblemBuilder::build
-    // guarantees it, linear_program.rs:147-156); anything else is treated as a dense matrix.
-    if (n_slack == n) n_slack = 0;
-    for (uint64_t i = 0; i < m && n_slack; ++i) {
-        const double* row = A + i * lda + (n - n_slack);
-        for (uint64_t j = 0; j < n_slack; ++j)
-            if (row[j] != ((i == j) ? 1.0 : 0.0)) { n_slack = 0; break; }
-    }
-    LP_HIP(hipSetDevice(c->device));
-    const uint64_t nx = n - n_slack;
-    const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK), npa = (int)round_up(nx, BK);
-    if (!c->has_problem || mp != c->mp || np != c->np || npa != c->npa) {
-        LP_HIP(hipStreamSynchronize(c->st));
-        free_list(c->allocs);
-        factor_plan_destroy(c->plan);
-        c->alloc_bytes.clear();
-        c->has_problem = false;
-        c->mp = mp; c->np = np; c->npa = npa;
-        c->nsplit = mp / GEMVT_ROWS;
-        const uint64_t big = m > n ? m : n;
-        c->nblk = (int)((big + 255) / 256);
-        if (c->nblk > RED_STRIDE) c->nblk = RED_STRIDE;
-        VecArgs& v = c->va;
-        auto& L = c->allocs;
-        hipStream_t st = c->st;
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->A, (size_t)mp * npa, st));
-        double *bb, *ccv;
-        LP_TRY(dalloc(L, &c->alloc_bytes, &bb, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &ccv, (size_t)np, st));
-        v.b = bb; v.c = ccv;
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.x, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.y, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.z, (size_t)np, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dinv, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.xs, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.r1, (size_t)np, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.rD, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.p, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.u, (size_t)np, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dx, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.dz, (size_t)np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.dxdz, (size_t)np, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.rP, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.rP2, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.q, (size_t)mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.dy, (size_t)mp, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.Ax, (size_t)mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.W, (size_t)2 * np, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.R, (size_t)2 * mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->Y, (size_t)2 * mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->ATpart, (size_t)c->nsplit * 2 * np, st));
-        v.ATpart = c->ATpart;
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.S, (size_t)64, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.red, (size_t)RED_SLOTS * RED_STRIDE, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.status, 1, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &v.potrf_info, 1, st)); LP_TRY(dalloc(L, &c->alloc_bytes, &v.flags, 1, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->M, (size_t)mp * mp, st));
-        LP_HIP(factor_plan_create(c->plan, c->M, mp, mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->tau, (size_t)mp, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->gs, (size_t)8, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->xout, (size_t)np, st));
-        const int nt = mp / TILE;
-        std::vector<int2> order = adat_tile_order(nt);
-        c->ntiles = (int)order.size();
-        c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu);
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->tile_list, order.size(), st));
-        LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        LP_TRY(dalloc(L, &c->alloc_bytes, &c->ws, (size_t)2 * c->adat_nwg * TILE * TILE, st));
-        LP_HIP(hipStreamSynchronize(st));  // `order` must outlive the copy
-        v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
-    } else {
-        // same padded geometry: clear everything but the constant tile list, so no stale (possibly
-        // non-finite) value of a previous problem can sit in a padding lane
-        for (size_t i = 0; i < c->allocs.size(); ++i)
-            if (c->allocs[i] != (void*)c->tile_list)
-                LP_HIP(hipMemsetAsync(c->allocs[i], 0, c->alloc_bytes[i], c->st));
-    }
-    c->m = m; c->n = n; c->c0 = c0;
-    c->ns = (int)n_slack; c->nx = (int)nx;
-    c->va.n = (int)n; c->va.m = (int)m;
-    c->va.n_total = (long long)n; c->va.gs = nullptr; c->colsplit = false;   // lpipm_upload_nsplit overrides
-    LP_HIP(hipMemcpy2DAsync(c->A, (size_t)npa * sizeof(double), A, (size_t)lda * sizeof(double),
-                            (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, c->st));
-    LP_HIP(hipMemcpyAsync((void*)c->va.b, b, m * sizeof(double), hipMemcpyHostToDevice, c->st));
-    LP_HIP(hipMemcpyAsync((void*)c->va.c, cc, n * sizeof(double), hipMemcpyHostToDevice, c->st));
-    LP_HIP(hipStreamSynchronize(c->st));
-    c->has_problem = true;
-    return LPIPM_OK;
+    return upload_impl(c, 1, m, n, &A, lda, &b, &cc, &c0, n_slack);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Y = add + A.W and Upart = row-split slabs of A^T.V on the stored structural columns, plus the
 // identity block of the slack columns
-static hipError_t ctx_gemv_n(lpipm_ctx* c, int nrhs, const double* W, const double* add0, const double* add1, double* Y) {
-    hipError_t e = launch_gemv_n(c->A, c->npa, (int)c->m, c->npa, nrhs, W, c->np, add0, add1, Y, c->mp, c->st);
+static hipError_t ctx_gemv_n(lpipm_ctx* c, int nrhs, const double* W, const double* add0, const double* add1, double* Y,
+                             const Batch& bt) {
+    hipError_t e = launch_gemv_n(c->A, c->npa, (int)c->m, c->npa, nrhs, W, c->np, add0, add1, Y, c->mp, c->st, 1.0, bt);
     if (e != hipSuccess) return e;
-    return launch_slack_n(c->ns, c->nx, nrhs, W, c->np, Y, c->mp, c->st);
+    return launch_slack_n(c->ns, c->nx, nrhs, W, c->np, Y, c->mp, c->st, bt);
 }
-static hipError_t ctx_gemv_t(lpipm_ctx* c, int nrhs, const double* V) {
-    hipError_t e = launch_gemv_t(c->A, c->npa, c->mp, c->npa, nrhs, V, c->mp, c->ATpart, c->st, c->np);
+static hipError_t ctx_gemv_t(lpipm_ctx* c, int nrhs, const double* V, const Batch& bt) {
+    hipError_t e = launch_gemv_t(c->A, c->npa, c->mp, c->npa, nrhs, V, c->mp, c->ATpart, c->st, c->np, bt);
     if (e != hipSuccess) return e;
-    return launch_slack_t(c->ns, c->nx, nrhs, c->nsplit, V, c->mp, c->ATpart, c->np, c->st);
+    return launch_slack_t(c->ns, c->nx, nrhs, c->nsplit, V, c->mp, c->ATpart, c->np, c->st, bt);
 }
 
 // M = A . diag(dinv) . A^T, lower tiles (newton_equations.rs:54-57)
-static hipError_t run_adat(lpipm_ctx* c) {
+static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     GemmArgs g{};
     g.P = c->A; g.ldp = c->npa; g.Q = c->A; g.ldq = c->npa; g.s = c->va.dinv;
     g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
-    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg;
+    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt;
     hipError_t e = launch_gemm_nt(g, c->st);
     if (e != hipSuccess) return e;
-    return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st);   // + diag(D_slack)
+    return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
 }
 
 static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol) {
     VecArgs& v = c->va;
     // A.x and A^T.y at the current point (residual.rs:23,25)
     XRank xr{xrank_fn, c};
-    LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax));
+    LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax, c->bt));
     LP_TRY(ctx_allreduce(c, v.Ax, c->m, 0));          // n-split: A.x = sum over ranks of A_g.x_g
-    LP_HIP(ctx_gemv_t(c, 1, v.y));
+    LP_HIP(ctx_gemv_t(c, 1, v.y, c->bt));
     prof_mark(c, T_GEMV);
-    LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->c0, c->st, c->colsplit ? &xr : nullptr));
+    LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->st, c->colsplit ? &xr : nullptr));
     LP_HIP(hipGetLastError());
+    return LPIPM_OK;
+}
+
+// status records of all LPs of the context -> pinned host array (96 bytes each)
+static int copy_status(lpipm_ctx* c) {
+    if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, c->va.status, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
+    else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), c->va.status, c->bstride, sizeof(StatusRec), (size_t)c->B,
+                                 hipMemcpyDeviceToHost, c->st));
     return LPIPM_OK;
 }
 
@@ -390,7 +452,8 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_VEC);
     XRank xr_{xrank_fn, c};
     const XRank* xr = c->colsplit ? &xr_ : nullptr;
-    LP_HIP(run_adat(c));                                                   // newton_equations.rs:55-57
+    const Batch& bt = c->bt;
+    LP_HIP(run_adat(c, bt));                                               // newton_equations.rs:55-57
     if (c->colsplit && c->world > 1) {                                     // n-split: M = sum_g A_g D_g A_g^T
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
         LP_TRY(ctx_allreduce(c, c->mpack, c->mpack_count, 0));
@@ -398,22 +461,22 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     }
     prof_mark(c, T_ADAT);
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
-    if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st));   // :129-131
+    if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
     else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
     if (!c->colsplit) {
-        LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R));  // :220
+        LP_HIP(ctx_gemv_n(c, 2, v.W, v.b, v.rP, v.R, bt));  // :220
     } else {   // the addend r2 enters once, after the cross-rank sum of the column-split products
-        LP_HIP(ctx_gemv_n(c, 2, v.W, nullptr, nullptr, v.R));
+        LP_HIP(ctx_gemv_n(c, 2, v.W, nullptr, nullptr, v.R, bt));
         LP_TRY(ctx_allreduce(c, v.R, (uint64_t)2 * c->mp, 0));
         vec_add_rows((int)c->m, 2, v.R, c->mp, v.b, v.rP, st);
     }
     prof_mark(c, T_GEMV);
-    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st));           // :221, :154
+    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st, bt));       // :221, :154
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 2, v.R, v.potrf_info, st));   // :155-166
     prof_mark(c, T_TRSV);
-    LP_HIP(ctx_gemv_t(c, 2, v.R));                  // :223
+    LP_HIP(ctx_gemv_t(c, 2, v.R, bt));              // :223
     prof_mark(c, T_GEMV);
     LP_TRY(vec_pq_uv(v, st, xr));                       // :223, delta.rs:29-32,38
     LP_TRY(vec_delta(v, 0, ip, 1.0, st, xr));           // delta.rs:33-37, feasible_point.rs:134-136
@@ -421,25 +484,51 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_VEC);
     // corrector: only the second sym_solve changes
     if (!c->colsplit) {
-        LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R));
+        LP_HIP(ctx_gemv_n(c, 1, v.W, v.rP2, nullptr, v.R, bt));
     } else {
-        LP_HIP(ctx_gemv_n(c, 1, v.W, nullptr, nullptr, v.R));
+        LP_HIP(ctx_gemv_n(c, 1, v.W, nullptr, nullptr, v.R, bt));
         LP_TRY(ctx_allreduce(c, v.R, c->mp, 0));
         vec_add_rows((int)c->m, 1, v.R, c->mp, v.rP2, nullptr, st);
     }
     prof_mark(c, T_GEMV);
-    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st));
+    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st, bt));
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 1, v.R, v.potrf_info, st));
     prof_mark(c, T_TRSV);
-    LP_HIP(ctx_gemv_t(c, 1, v.R));
+    LP_HIP(ctx_gemv_t(c, 1, v.R, bt));
     prof_mark(c, T_GEMV);
     LP_TRY(vec_uv_corr(v, st, xr));
     LP_TRY(vec_delta(v, 1, ip, o->alpha0, st, xr));     // mod.rs:216-221
     vec_step(v, ip, st);                    // feasible_point.rs:76-106
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
-    LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+    LP_TRY(copy_status(c));
     prof_mark(c, T_VEC);
+    return LPIPM_OK;
+}
+
+// The ~100 launches of one iteration replayed as one hipGraph launch: the sequence and every argument
+// are the same from iteration to iteration (only `ip` differs, on the first one).  Capturing does not
+// execute anything, so the first use of a key costs one capture + instantiate and then runs the graph.
+static int run_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
+    const bool graphable = c->use_graph == 1 && !c->profiling && !c->colsplit && o->solver_type == LPIPM_SOLVER_CHOLESKY;
+    if (!graphable) return enqueue_iteration(c, ip, o);
+    for (auto& g : c->graphs)
+        if (g.ip == ip && g.alpha0 == o->alpha0 && g.tol == o->tol) {
+            LP_HIP(hipGraphLaunch(g.exec, c->st));
+            return LPIPM_OK;
+        }
+    LP_HIP(hipStreamBeginCapture(c->st, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_iteration(c, ip, o);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->st, &graph);
+    if (rc != LPIPM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    LP_HIP(e);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    LP_HIP(ei);
+    c->graphs.push_back({ip, o->alpha0, o->tol, exec});
+    LP_HIP(hipGraphLaunch(exec, c->st));
     return LPIPM_OK;
 }
 
@@ -455,10 +544,12 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
     if (o->solver_type < 0 || o->solver_type > 2) return LPIPM_INVALID_PARAMETER;
     if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    if (c->B != 1) return LPIPM_ERR_BAD_ARGUMENT;   // a lockstep batch is solved by solve_lockstep
     if (o->solver_type != LPIPM_SOLVER_CHOLESKY && c->mp > 16384) return LPIPM_ERR_UNSUPPORTED;  // QR solve keeps the rhs in LDS
     LP_HIP(hipSetDevice(c->device));
     VecArgs& v = c->va;
     hipStream_t st = c->st;
+    if (c->use_graph < 0) { const char* g = getenv("LPIPM_GRAPH"); c->use_graph = (g && g[0] == '1') ? 1 : 0; }
     for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
     c->times = lpipm_phase_times{};
     c->nmarks = 0;
@@ -468,7 +559,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     vec_blind_start(v, st);                               // feasible_point.rs:24-31
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));  // feasible_point.rs:32, mod.rs:206
-    LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+    LP_TRY(copy_status(c));
     prof_mark(c, T_VEC);
     LP_HIP(hipStreamSynchronize(st));
     prof_collect(c);
@@ -480,7 +571,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     int ret = LPIPM_ITERATION_LIMIT;
     uint64_t iteration = 0;
     for (iteration = 1; iteration <= o->max_iter; ++iteration) {   // mod.rs:213
-        LP_TRY(enqueue_iteration(c, ip, o));
+        LP_TRY(run_iteration(c, ip, o));
         ++adat_launches;
         LP_HIP(hipStreamSynchronize(st));
         prof_collect(c);
@@ -502,11 +593,11 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     if (ret == LPIPM_ITERATION_LIMIT) iteration = o->max_iter;
     if (ret == LPIPM_OK || ret == LPIPM_ITERATION_LIMIT) {
         XRank xrf{xrank_fn, c};
-        LP_TRY(vec_final_x(v, c->xout, c->c0, st, c->colsplit ? &xrf : nullptr));   // mod.rs:231/238, :165
+        LP_TRY(vec_final_x(v, c->xout, st, c->colsplit ? &xrf : nullptr));   // mod.rs:231/238, :165
         LP_HIP(hipGetLastError());
         if (x_dev) LP_HIP(hipMemcpyAsync(x_dev, c->xout, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
         if (x_host) LP_HIP(hipMemcpyAsync(x_host, c->xout, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
-        LP_HIP(hipMemcpyAsync(c->status_host, v.status, sizeof(StatusRec), hipMemcpyDeviceToHost, st));
+        LP_TRY(copy_status(c));
         if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
         LP_HIP(hipStreamSynchronize(st));
         if (fun_out) *fun_out = c->status_host->obj;
@@ -656,7 +747,7 @@ extern "C" int lpipm_k_adat(lpipm_ctx* c, const double* dinv, double* M_out, int
     if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
     LP_HIP(hipSetDevice(c->device));
     LP_HIP(hipMemcpyAsync(c->va.dinv, dinv, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
-    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int { LP_HIP(run_adat(c)); return LPIPM_OK; }));
+    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int { LP_HIP(run_adat(c, Batch{})); return LPIPM_OK; }));
     LP_HIP(hipMemcpy2DAsync(M_out, c->m * sizeof(double), c->M, (size_t)c->mp * sizeof(double),
                             c->m * sizeof(double), c->m, hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
@@ -675,7 +766,13 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kY, (size_t)2 * mp, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->ktau, (size_t)mp, c->st));
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, c->st));
+    Arena measure;
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st));
+    char* kar = nullptr;
+    LP_TRY(dalloc(c->kallocs, nullptr, &kar, measure.off + 256, c->st));   // zeroed
+    Arena real;
+    real.base = kar;
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st));
     c->kmp = mp;
     return LPIPM_OK;
 }
@@ -800,7 +897,7 @@ extern "C" int lpipm_k_gemv_n(lpipm_ctx* c, int nrhs, const double* W, double* Y
     LP_HIP(hipMemcpy2DAsync(c->va.W, (size_t)c->np * sizeof(double), W, c->n * sizeof(double), c->n * sizeof(double),
                             nrhs, hipMemcpyHostToDevice, c->st));
     LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
-        LP_HIP(ctx_gemv_n(c, nrhs, c->va.W, nullptr, nullptr, c->va.R));
+        LP_HIP(ctx_gemv_n(c, nrhs, c->va.W, nullptr, nullptr, c->va.R, Batch{}));
         return LPIPM_OK;
     }));
     LP_HIP(hipMemcpy2DAsync(Y, c->m * sizeof(double), c->va.R, (size_t)c->mp * sizeof(double), c->m * sizeof(double),
@@ -817,7 +914,7 @@ extern "C" int lpipm_k_gemv_t(lpipm_ctx* c, int nrhs, const double* V, double* U
     LP_HIP(hipMemcpy2DAsync(c->va.R, (size_t)c->mp * sizeof(double), V, c->m * sizeof(double), c->m * sizeof(double),
                             nrhs, hipMemcpyHostToDevice, c->st));
     LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
-        LP_HIP(ctx_gemv_t(c, nrhs, c->va.R));
+        LP_HIP(ctx_gemv_t(c, nrhs, c->va.R, Batch{}));
         LP_HIP(launch_gemv_t_reduce(c->ATpart, c->nsplit, nrhs, c->np, c->va.W, c->np, c->st));
         return LPIPM_OK;
     }));

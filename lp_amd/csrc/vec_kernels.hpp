@@ -10,7 +10,9 @@ constexpr int RED_SLOTS  = 8;
 // device scalar block S
 enum {
     S_TAU = 0, S_KAPPA, S_MU, S_RG, S_GAMMA, S_ETA, S_RHAT_G, S_RHAT_TK, S_DTAU, S_DKAPPA,
-    S_ALPHA_PRED, S_ALPHA, S_CP, S_BQ, S_RP0, S_RD0, S_RG0, S_RMU0, S_COUNT
+    S_ALPHA_PRED, S_ALPHA, S_CP, S_BQ, S_RP0, S_RD0, S_RG0, S_RMU0,
+    S_C0,   // the constant of the objective (written at upload; every LP of a batch has its own)
+    S_COUNT
 };
 enum { ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_UNBOUNDED = 2, ST_UNFINISHED = 3 };  // indicators.rs:85-90
 enum { FLAG_NAN_PQ = 1 };
@@ -39,6 +41,9 @@ struct VecArgs {
     StatusRec* status;
     int32_t *potrf_info;
     int *flags;
+    int *done;        // set by k_scalar_indicators when the LP has reached a final status; cleared by k_blind_start
+    int bcount;       // lockstep batch: LPs per launch (gridDim.z); every pointer above is LP 0's,
+    long long bstride;//   LP z's is bstride bytes * z further
 };
 
 // n-split mode (a.gs != nullptr): between a vector kernel and the scalar kernel that consumes its
@@ -49,14 +54,14 @@ struct XRank {
     void* self;
 };
 void vec_blind_start(const VecArgs& a, hipStream_t st);
-int  vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, double c0, hipStream_t st, const XRank* xr = nullptr);
+int  vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr = nullptr);
 void vec_pred_setup(const VecArgs& a, hipStream_t st);
 int  vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
 int  vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
 int  vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr = nullptr);
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
 void vec_step(const VecArgs& a, int ip, hipStream_t st);
-int  vec_final_x(const VecArgs& a, double* xout, double c0, hipStream_t st, const XRank* xr = nullptr);
+int  vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr = nullptr);
 // Y[q][i] += add_q[i] (i < m): the addend of a column-split A.w after its cross-rank sum
 // packed has mp*(mp+128)/2 doubles; dir 0 = M -> packed, 1 = packed -> M (mp a multiple of 128, ld even)
 void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st);
