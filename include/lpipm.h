@@ -152,6 +152,19 @@ int lpipm_set_collective(lpipm_ctx* ctx, int rank, int world, lpipm_allreduce_fn
 int lpipm_upload_nsplit(lpipm_ctx* ctx, uint64_t m, uint64_t n_total, uint64_t n_local, const double* A_local,
                         uint64_t lda, const double* b, const double* c_local, double c0);
 
+/* Lockstep batch: `count` LPs of ONE shape (m x n, dense) resident on the device at once; every kernel launch of
+ * the iteration covers all of them, so the ~100 dependent launches per iteration are paid once per batch
+ * instead of once per LP.  lpipm_upload_lockstep replaces the context's problem; lpipm_solve_lockstep returns
+ * per-LP status (0 / LinearProgramError variants), fun, iterations and x / tau, exactly as `count` calls of
+ * lpipm_solve would (Cholesky arm only: LPIPM_ERR_UNSUPPORTED otherwise).  A[i]: m x n row-major, lda = n. */
+int lpipm_upload_lockstep(lpipm_ctx* ctx, uint64_t count, uint64_t m, uint64_t n, const double* const* A,
+                          const double* const* b, const double* const* c, const double* c0 /* nullable */);
+int lpipm_solve_lockstep(lpipm_ctx* ctx, const lpipm_opts* opts, double* const* x_slack_out, double* fun_out,
+                         uint64_t* iterations_out, int32_t* status_out);
+/* lpipm_solve_batch groups members of equal shape into lockstep batches: max_group -1 = auto (default, up to 64
+ * per group within the memory budget), 0 = never, > 0 = largest group. */
+int lpipm_set_batch_lockstep(lpipm_ctx* ctx, int max_group);
+
 /* Number of LPs of a batch in flight at once on the device (0 = auto, the default: 8 for members up
  * to m = 2048, else 2; 1 = strictly one after the other).  Members of a batch are independent, each in-flight member has its own stream and buffers. */
 int lpipm_set_batch_concurrency(lpipm_ctx* ctx, int nworkers);

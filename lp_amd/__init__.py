@@ -265,6 +265,40 @@ class Context:
         self.m, self.n = m, nl
         return self
 
+    def upload_lockstep(self, As, bs, cs, c0s=None):
+        """`len(As)` LPs of one shape resident at once (lpipm_upload_lockstep); solve with solve_lockstep."""
+        As = [_f64(A) for A in As]; bs = [_f64(b) for b in bs]; cs = [_f64(c) for c in cs]
+        K = len(As)
+        if K < 1 or len(bs) != K or len(cs) != K:
+            raise IncompatibleInputDimensions()
+        m, n = As[0].shape
+        for A, b, c in zip(As, bs, cs):
+            if A.shape != (m, n) or b.shape != (m,) or c.shape != (n,):
+                raise IncompatibleInputDimensions()
+        dp = C.POINTER(C.c_double)
+        arr = lambda lst: (dp * K)(*[_p(a) for a in lst])
+        c0 = (C.c_double * K)(*[float(v) for v in c0s]) if c0s is not None else None
+        _raise_for(_capi.lib().lpipm_upload_lockstep(self._h, K, m, n, arr(As), arr(bs), arr(cs), c0))
+        self._lock = (K, m, n, As, bs, cs)      # keep the host arrays alive only for the duration of the call chain
+        self.m, self.n = m, n
+        return self
+
+    def solve_lockstep(self, opts: "_capi.Opts"):
+        """-> list of (status, x_slack | None, fun, iterations), one per LP of the last upload_lockstep"""
+        K, m, n = self._lock[:3]
+        dp = C.POINTER(C.c_double)
+        xs = [np.full(n, np.nan) for _ in range(K)]
+        xp = (dp * K)(*[_p(x) for x in xs])
+        fun = (C.c_double * K)(); its = (C.c_uint64 * K)(); st = (C.c_int32 * K)()
+        rc = _capi.lib().lpipm_solve_lockstep(self._h, C.byref(opts), xp, fun, its, st)
+        if rc != _capi.OK:
+            _raise_for(rc)
+        out = []
+        for i in range(K):
+            has_x = st[i] in (_capi.OK, _capi.ITERATION_LIMIT)
+            out.append((int(st[i]), xs[i] if has_x else None, fun[i] if has_x else None, int(its[i])))
+        return out
+
     def solve_raw(self, opts: "_capi.Opts", want_log: bool = False, x_dev_ptr: int | None = None):
         """-> (status, x_slack | None, fun, iterations, log rows)"""
         x = None if x_dev_ptr is not None else np.full(self.n, np.nan)

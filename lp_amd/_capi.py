@@ -48,6 +48,9 @@ SYMBOLS = {
                                     C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
     "lpipm_set_collective": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, _vp]),
     "lpipm_upload_nsplit": (C.c_int, [_vp, _u64, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
+    "lpipm_upload_lockstep": (C.c_int, [_vp, _u64, _u64, _u64, _dpp, _dpp, _dpp, _dp]),
+    "lpipm_solve_lockstep": (C.c_int, [_vp, C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
+    "lpipm_set_batch_lockstep": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_batch_concurrency": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_profiling": (C.c_int, [_vp, C.c_int]),
     "lpipm_get_phase_times": (C.c_int, [_vp, C.POINTER(PhaseTimes)]),

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p0)
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
     TILE_THREAD_IDS
-    const int g = xcd_remap(blockIdx.x, gridDim.x);
+    // batch in XCD-major layout: the workgroup's index inside its LP is blockIdx.y and the LP already sits on one XCD
+    const int g = p.bk.xcd_major ? (int)blockIdx.y : xcd_remap(blockIdx.x, gridDim.x);
     const int KT = p.KT;
     const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
 
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
     const GemmK p = batch_shift(p0);
     const int KT = p.KT;
     const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
-    const int rt = blockIdx.x / FIX_SPLIT, chunk = blockIdx.x % FIX_SPLIT;
+    const int bx = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
+    const int rt = bx / FIX_SPLIT, chunk = bx % FIX_SPLIT;
     const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
     const long long it0 = (long long)rt * KT, it1 = it0 + KT;
     const int g_lo = wg_owner(it0, total, p.nwg), g_hi = wg_owner(it1 - 1, total, p.nwg);
@@ -417,8 +419,12 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
         else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         return hipGetLastError();
     }
-    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, dim3(a.nwg, 1, B), dim3(256), 0, st, k);
-    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, dim3(a.nwg, 1, B), dim3(256), 0, st, k);
+    // a batch of a multiple of 8 LPs: one LP per XCD at a time (see BatchK)
+    const bool xm = B >= 8 && B % 8 == 0;
+    k.bk.xcd_major = xm ? 1 : 0;
+    const dim3 grid = xm ? dim3(8, a.nwg, B / 8) : dim3(a.nwg, 1, B);
+    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
+    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, grid, dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // remainder tiles: a split exists unless every workgroup boundary falls on a tile boundary
@@ -427,7 +433,8 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     bool split = false;
     for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
     if (split) {
-        hipLaunchKernelGGL(gemm_nt_fixup_kernel, dim3(nrem * FIX_SPLIT, 1, B), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(gemm_nt_fixup_kernel, xm ? dim3(8, nrem * FIX_SPLIT, B / 8) : dim3(nrem * FIX_SPLIT, 1, B), dim3(256), 0,
+                           st, k);
         e = hipGetLastError();
     }
     return e;

@@ -55,14 +55,15 @@ int plan_merges(int sb, int lo, int hi, std::vector<Merge>& out, size_t& tcursor
 }  // namespace
 
 hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build,
-                              hipStream_t st) {
+                              hipStream_t st, int super_w) {
     factor_plan_destroy(plan);
     plan.mp = mp;
+    plan.super_w = super_w;
     hipError_t e;
-    for (int r0 = 0; r0 < mp; r0 += SUPER) {
+    for (int r0 = 0; r0 < mp; r0 += super_w) {
         SuperBlock s{};
         s.row0 = r0;
-        s.size = mp - r0 < SUPER ? mp - r0 : SUPER;
+        s.size = mp - r0 < super_w ? mp - r0 : super_w;
         s.inv = arena.take<double>((size_t)s.size * s.size);
         s.invT = arena.take<double>((size_t)s.size * s.size);
         plan.sbs.push_back(s);
@@ -76,7 +77,7 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
     }
     double* tws = arena.take<double>(tcursor);
     // slabs of the backward sweep's transposed panel products: (rows below / 128) x 2 rhs x SUPER
-    plan.tpart = arena.take<double>((size_t)(mp / GEMVT_ROWS + 1) * 2 * SUPER);
+    plan.tpart = arena.take<double>((size_t)(mp / GEMVT_ROWS + 1) * 2 * super_w);
     if (!build) return hipSuccess;
 
     std::vector<GemmTileDesc> descs;

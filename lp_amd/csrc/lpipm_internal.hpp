@@ -39,19 +39,25 @@ struct Batch {
     long long stride = 0;
     const int* done = nullptr;
 };
-struct BatchK { long long stride; const int* done; };   // the part a kernel needs
-inline BatchK batch_k(const Batch& b) { return BatchK{b.stride, b.done}; }
+// The part a kernel needs.  xcd_major (A.D.A^T only, count a multiple of 8): grid = (8, workgroups per LP,
+// count / 8) and LP = 8*blockIdx.z + blockIdx.x -- workgroups are dealt to the 8 XCDs round-robin along x,
+// so all workgroups of one LP share one XCD's L2 and re-use each other's panels of A.
+struct BatchK { long long stride; const int* done; int xcd_major; };
+inline BatchK batch_k(const Batch& b) { return BatchK{b.stride, b.done, 0}; }
 #ifdef __HIPCC__
+__device__ __forceinline__ long long batch_lp(const BatchK& b) {
+    return b.xcd_major ? (long long)blockIdx.z * 8 + blockIdx.x : (long long)blockIdx.z;
+}
 __device__ __forceinline__ bool batch_done(const BatchK& b) {
-    return b.done && *(const int*)((const char*)b.done + (long long)blockIdx.z * b.stride) != 0;
+    return b.done && *(const int*)((const char*)b.done + batch_lp(b) * b.stride) != 0;
 }
 template <typename T>
 __device__ __forceinline__ T* batch_ptr(T* p, const BatchK& b) {   // null stays null
-    return p ? (T*)((char*)p + (long long)blockIdx.z * b.stride) : p;
+    return p ? (T*)((char*)p + batch_lp(b) * b.stride) : p;
 }
 template <typename T>
 __device__ __forceinline__ const T* batch_ptr(const T* p, const BatchK& b) {
-    return p ? (const T*)((const char*)p + (long long)blockIdx.z * b.stride) : p;
+    return p ? (const T*)((const char*)p + batch_lp(b) * b.stride) : p;
 }
 #endif
 
@@ -111,7 +117,7 @@ int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 // The factor L is consumed through explicit inverses of its diagonal SUPER-blocks (up to 1024 wide):
 // a triangular solve is then a handful of fully parallel mat-vec launches instead of mp/128
 // serialized block steps.  The plan owns the inverse storage and the static launch descriptors.
-constexpr int SUPER = 1024;  // super-block width (multiple of NB)
+constexpr int SUPER = 1024;  // default super-block width (multiple of NB)
 struct SuperBlock {
     int row0, size;          // first row/column of the diagonal super-block, its width (multiple of NB)
     double* inv;             // size x size row-major: inv(L_ss)   (lower triangular, zeros above)
@@ -119,6 +125,9 @@ struct SuperBlock {
 };
 struct FactorPlan {
     int mp = 0;
+    int super_w = SUPER;     // width of the diagonal super-blocks whose inverses are formed: wider = fewer, fully
+                             // parallel solve steps, but the merge GEMMs cost flops (a batch that already fills
+                             // the chip prefers 512)
     std::vector<SuperBlock> sbs;
     GemmTileDesc* descs_dev = nullptr;           // grouped-GEMM tiles of all merge stages (own allocation, shared by a batch)
     std::vector<std::pair<int, int>> stages;     // (first descriptor, count) per launch, in order
@@ -131,7 +140,8 @@ struct FactorPlan {
 // Takes the inverse storage for an mp x mp factor living at (L, ld) from the arena (which must be zeroed:
 // the never-written halves of the triangular inverses are read as zeros) and, when `build`, uploads the
 // merge descriptors.  build == false: sizing pass over a measuring arena, nothing is allocated.
-hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build, hipStream_t st);
+hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build, hipStream_t st,
+                              int super_w = SUPER);
 void factor_plan_destroy(FactorPlan& plan);
 
 // ---------------------------------------------------------------- Cholesky (kernels_potrf.hip)

@@ -75,6 +75,7 @@ struct lpipm_ctx {
     // batch mode: extra contexts (own stream + buffers) driven by host threads, see lpipm_solve_batch
     std::vector<lpipm_ctx*> workers;
     int batch_concurrency = 0;   // 0 = auto
+    int lockstep_max = -1;       // lpipm_solve_batch: -1 auto, 0 never group same-shape members, > 0 largest group
     // captured iteration (hipGraph): one executable graph per (ip, options) key, valid while the buffers live
     struct IterGraph { int ip; double alpha0, tol; hipGraphExec_t exec; };
     std::vector<IterGraph> graphs;
@@ -291,7 +292,9 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.status = ar.take<StatusRec>(1);
     v.potrf_info = ar.take<int32_t>(1); v.flags = ar.take<int>(1); v.done = ar.take<int>(1);
     c->M = ar.take<double>(mp * mp);
-    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st));
+    // a batch that fills the chip is flop-bound: the last doubling level of the inverse (1024) costs more than the
+    // two extra solve steps it saves
+    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, c->B >= 8 ? 512 : SUPER));
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
@@ -337,8 +340,17 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         c->ntiles = (int)order.size();
         // workgroups per LP of the A.D.A^T launch: stream-K over the chip's share of one LP; a batch that
         // fills the chip with whole tiles needs no k-split (and no slabs)
-        c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, count == 1 ? c->num_cu : c->num_cu / count);
-        if (count > 1 && c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
+        if (count == 1) c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu);
+        else if ((long long)count * c->ntiles >= 2LL * c->num_cu) {
+            // more tiles than resident workgroups: each LP gets its share of the 2*CUs slots and stream-K
+            // balances its tiles over them (no tail round of a few leftover tiles)
+            c->adat_nwg = 2 * c->num_cu / count;
+            if (c->adat_nwg < 1) c->adat_nwg = 1;
+            if (c->adat_nwg > c->ntiles) c->adat_nwg = c->ntiles;
+        } else {
+            c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu / count);
+            if (c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
+        }
         Arena measure;
         LP_TRY(layout_problem(c, measure, false));
         c->bstride = round_up(measure.off, 4096);
@@ -628,26 +640,185 @@ extern "C" int lpipm_solve_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev
     return solve_impl(c, o, nullptr, x_dev_out, fun_out, iterations_out, log);
 }
 
-// A shard of independent LPs on one device.  Small LPs are latency-bound (the factorisation's
-// diagonal chain keeps 1 of 256 CUs busy), so `batch_concurrency` contexts -- each with its own
-// stream and buffers, each driven by its own host thread -- solve different members at the same
-// time; independent streams need no cross-stream synchronisation.  Members are handed out through
-// an atomic counter; every member's result depends only on its own inputs, so the outcome is
-// identical to solving them one after the other.
+// ------------------------------------------------------------------------------------------------
+// Lockstep batch: B LPs of one shape resident at once (upload_impl with count = B), every launch of the
+// iteration covering all of them (gridDim.z = B).  The ~100 dependent launches per iteration -- the
+// latency floor of a small LP -- are then paid once per B LPs.  LPs finish at different iterations:
+// k_scalar_indicators sets an LP's `done` word on the conditions that end the reference's loop
+// (mod.rs:215, :231-233) and every later kernel skips it, so its iterate stays what it was; the host
+// mirrors the same decisions from the status records to count iterations and pick the return codes.
+static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_out, double* fun_out,
+                          uint64_t* its_out, int32_t* status_out) {
+    if (!c || !o || !x_out || !status_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!(o->alpha0 > 0.0) || !(o->alpha0 < 1.0)) return LPIPM_INVALID_PARAMETER;   // mod.rs:118-128
+    if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
+    if (o->solver_type != LPIPM_SOLVER_CHOLESKY) return LPIPM_ERR_UNSUPPORTED;      // the QR arms are single-LP
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    if (c->colsplit || c->profiling) return LPIPM_ERR_UNSUPPORTED;
+    LP_HIP(hipSetDevice(c->device));
+    const int B = c->B;
+    VecArgs& v = c->va;
+    hipStream_t st = c->st;
+    vec_blind_start(v, st);                                                  // feasible_point.rs:24-31
+    LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));                  // feasible_point.rs:32, mod.rs:206
+    LP_HIP(hipStreamSynchronize(st));
+    std::vector<int> ret((size_t)B, -1);                                     // -1: still iterating
+    std::vector<uint64_t> its((size_t)B, 0);
+    int running = B, ip = o->ip ? 1 : 0;
+    for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
+        LP_TRY(enqueue_iteration(c, ip, o));
+        LP_HIP(hipStreamSynchronize(st));
+        ip = 0;                                                              // mod.rs:223
+        for (int i = 0; i < B; ++i) {
+            if (ret[i] >= 0) continue;
+            const StatusRec& s = c->status_host[i];
+            if (s.potrf_info != 0 || (s.flags & FLAG_NAN_PQ)) ret[i] = LPIPM_NUMERICAL_PROBLEM;   // mod.rs:215
+            else if (s.status == ST_OPTIMAL) ret[i] = LPIPM_OK;              // mod.rs:231
+            else if (s.status == ST_INFEASIBLE) ret[i] = LPIPM_INFEASIBLE;   // :232
+            else if (s.status == ST_UNBOUNDED) ret[i] = LPIPM_UNBOUNDED;     // :233
+            if (ret[i] >= 0) { its[i] = iteration; --running; }
+        }
+    }
+    for (int i = 0; i < B; ++i)
+        if (ret[i] < 0) { ret[i] = LPIPM_ITERATION_LIMIT; its[i] = o->max_iter; }   // mod.rs:237-239
+    LP_TRY(vec_final_x(v, c->xout, st, nullptr));                            // mod.rs:231/238, :165 (every LP)
+    LP_TRY(copy_status(c));
+    for (int i = 0; i < B; ++i)
+        if ((ret[i] == LPIPM_OK || ret[i] == LPIPM_ITERATION_LIMIT) && x_out[i])
+            LP_HIP(hipMemcpyAsync(x_out[i], (const char*)c->xout + (size_t)i * c->bstride, c->n * sizeof(double),
+                                  hipMemcpyDeviceToHost, st));
+    LP_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < B; ++i) {
+        status_out[i] = ret[i];
+        const bool has_x = ret[i] == LPIPM_OK || ret[i] == LPIPM_ITERATION_LIMIT;
+        if (fun_out) fun_out[i] = has_x ? c->status_host[i].obj : NAN;
+        if (its_out) its_out[i] = its[i];
+    }
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_upload_lockstep(lpipm_ctx* c, uint64_t count, uint64_t m, uint64_t n, const double* const* A,
+                                     const double* const* b, const double* const* cc, const double* c0) {
+    if (count < 1 || count > 4096) return LPIPM_ERR_BAD_ARGUMENT;
+    return upload_impl(c, (int)count, m, n, A, n, b, cc, c0, 0);
+}
+extern "C" int lpipm_solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_slack_out, double* fun_out,
+                                    uint64_t* iterations_out, int32_t* status_out) {
+    return solve_lockstep(c, o, x_slack_out, fun_out, iterations_out, status_out);
+}
+
+// A shard of independent LPs on one device.
+//  1. Members of one shape (>= 2 of them, Cholesky arm) are solved as lockstep batches, in chunks that fit
+//     the memory budget: one launch per kernel for the whole chunk.
+//  2. The rest (odd shapes, QR arms) are latency-bound one by one (the factorisation's diagonal chain
+//     keeps 1 of 256 CUs busy), so `batch_concurrency` contexts -- each with its own stream and buffers,
+//     each driven by its own host thread -- solve different members at the same time; independent
+//     streams need no cross-stream synchronisation.  Members are handed out through an atomic counter.
+// Every member's result depends only on its own inputs.
 extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
                                  const double* const* A, const double* const* b, const double* const* cc,
                                  const double* c0, const lpipm_opts* o, double* const* x_slack_out,
                                  double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
     if (!c || !o || (count && (!m || !n || !A || !b || !cc || !x_slack_out || !status_out)))
         return LPIPM_ERR_BAD_ARGUMENT;
+    std::vector<uint64_t> rest;                      // members left to the one-by-one path
+    if (c->lockstep_max != 0 && o->solver_type == LPIPM_SOLVER_CHOLESKY) {
+        LP_HIP(hipSetDevice(c->device));
+        std::vector<char> taken(count, 0);
+        for (uint64_t i = 0; i < count; ++i) {
+            if (taken[i]) continue;
+            std::vector<uint64_t> grp;
+            for (uint64_t j = i; j < count; ++j)
+                if (!taken[j] && m[j] == m[i] && n[j] == n[i]) grp.push_back(j);
+            if (grp.size() < 2) continue;
+            for (uint64_t j : grp) taken[j] = 1;
+            // chunk size: the configured maximum, and what fits in ~60 % of the free memory (two chunks are
+            // resident: one being solved, the next one being uploaded)
+            size_t free_b = 0, total_b = 0;
+            LP_HIP(hipMemGetInfo(&free_b, &total_b));
+            free_b += c->arena_bytes;                // the current arena is released before the next one is made
+            const double mp = (double)round_up(m[i], NB), np = (double)round_up(n[i], BK);
+            const double per_lp = 8.0 * (mp * np + 4.5 * mp * mp + 16.0 * np + 2.0 * TILE * TILE * 8.0) + (1 << 20);
+            size_t chunk;
+            if (c->lockstep_max > 0) chunk = (size_t)c->lockstep_max;
+            else if (grp.size() > 32) chunk = 32;
+            else if (grp.size() >= 16) chunk = (grp.size() + 1) / 2;   // two chunks: the second upload hides behind the first solve
+            else chunk = grp.size();
+            const size_t fit = (size_t)(0.3 * (double)free_b / per_lp);
+            if (chunk > fit) chunk = fit;
+            if (chunk < 2) { for (uint64_t j : grp) rest.push_back(j); continue; }
+            // chunks of the group; a last chunk of one member goes to the one-by-one path
+            struct Chunk { size_t k0, g; std::vector<const double*> A, b, c; std::vector<double> c0; };
+            std::vector<Chunk> chunks;
+            for (size_t k0 = 0; k0 < grp.size(); k0 += chunk) {
+                const size_t g = (k0 + chunk < grp.size() ? k0 + chunk : grp.size()) - k0;
+                if (g < 2) { rest.push_back(grp[k0]); continue; }
+                Chunk ch{k0, g, std::vector<const double*>(g), std::vector<const double*>(g), std::vector<const double*>(g),
+                         std::vector<double>(g, 0.0)};
+                for (size_t k = 0; k < g; ++k) {
+                    const uint64_t j = grp[k0 + k];
+                    ch.A[k] = A[j]; ch.b[k] = b[j]; ch.c[k] = cc[j];
+                    if (c0) ch.c0[k] = c0[j];
+                }
+                chunks.push_back(std::move(ch));
+            }
+            // Pipeline over two contexts: while chunk q is being solved on one, a helper thread uploads
+            // chunk q+1 into the other (host staging + copy engine vs. compute: the PCIe time of a large
+            // batch hides behind the solves).
+            lpipm_ctx* pipe[2] = {c, nullptr};
+            if (chunks.size() > 1) {
+                if (c->workers.empty()) {
+                    lpipm_ctx* w = nullptr;
+                    const int rcw = lpipm_create(c->device, &w);
+                    if (rcw != LPIPM_OK) return rcw;
+                    c->workers.push_back(w);
+                }
+                pipe[1] = c->workers[0];
+            }
+            auto upload_chunk = [&](lpipm_ctx* w, const Chunk& ch) -> int {
+                (void)hipSetDevice(w->device);
+                return upload_impl(w, (int)ch.g, m[i], n[i], ch.A.data(), n[i], ch.b.data(), ch.c.data(), ch.c0.data(), 0);
+            };
+            int rc_up = chunks.empty() ? LPIPM_OK : upload_chunk(pipe[0], chunks[0]);
+            for (size_t q = 0; q < chunks.size(); ++q) {
+                const Chunk& ch = chunks[q];
+                lpipm_ctx* w = pipe[q & 1];
+                int rc_next = LPIPM_OK;
+                std::thread up;
+                if (q + 1 < chunks.size()) up = std::thread([&, q] { rc_next = upload_chunk(pipe[(q + 1) & 1], chunks[q + 1]); });
+                const size_t g = ch.g;
+                std::vector<double> gfun(g, NAN);
+                std::vector<double*> gx(g);
+                std::vector<uint64_t> gits(g, 0);
+                std::vector<int32_t> gst(g, 0);
+                for (size_t k = 0; k < g; ++k) gx[k] = x_slack_out[grp[ch.k0 + k]];
+                int rc = rc_up;
+                if (rc == LPIPM_OK) rc = solve_lockstep(w, o, gx.data(), gfun.data(), gits.data(), gst.data());
+                if (up.joinable()) up.join();
+                if (rc >= 100) return rc;            // runtime failure: nothing sensible to continue with
+                for (size_t k = 0; k < g; ++k) {
+                    const uint64_t j = grp[ch.k0 + k];
+                    status_out[j] = rc == LPIPM_OK ? gst[k] : rc;     // e.g. Unconstrained / InvalidParameter for all
+                    if (fun_out) fun_out[j] = rc == LPIPM_OK ? gfun[k] : NAN;
+                    if (iterations_out) iterations_out[j] = rc == LPIPM_OK ? gits[k] : 0;
+                }
+                rc_up = rc_next;
+            }
+        }
+        for (uint64_t i = 0; i < count; ++i)
+            if (!taken[i]) rest.push_back(i);
+    } else {
+        for (uint64_t i = 0; i < count; ++i) rest.push_back(i);
+    }
+    if (rest.empty()) return LPIPM_OK;
     int nworkers = c->batch_concurrency;
     if (nworkers == 0) {   // auto: latency-bound sizes gain ~3x from 4-8 members in flight (measured at
                            // 1024x2048: 165 -> 513 LP/s); sizes that fill the chip by themselves do not
         uint64_t mmax = 0;
-        for (uint64_t i = 0; i < count; ++i) mmax = m[i] > mmax ? m[i] : mmax;
+        for (uint64_t i : rest) mmax = m[i] > mmax ? m[i] : mmax;
         nworkers = mmax <= 2048 ? 8 : 2;
     }
-    if ((uint64_t)nworkers > count) nworkers = (int)count;
+    if ((size_t)nworkers > rest.size()) nworkers = (int)rest.size();
     if (nworkers < 1) nworkers = 1;
     while ((int)c->workers.size() < nworkers - 1) {
         lpipm_ctx* w = nullptr;
@@ -662,8 +833,9 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
         lpipm_opts opts = *o;
         opts.disp = 0;   // interleaved tables from concurrent members would be unreadable
         for (;;) {
-            const uint64_t i = next.fetch_add(1);
-            if (i >= count || fatal.load() != LPIPM_OK) break;
+            const uint64_t k = next.fetch_add(1);
+            if (k >= rest.size() || fatal.load() != LPIPM_OK) break;
+            const uint64_t i = rest[k];
             int rc = lpipm_upload(w, m[i], n[i], A[i], n[i], b[i], cc[i], c0 ? c0[i] : 0.0);
             double fun = NAN;
             uint64_t it = 0;
@@ -679,6 +851,12 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
     run(c);
     for (std::thread& t : threads) t.join();
     return fatal.load();
+}
+
+extern "C" int lpipm_set_batch_lockstep(lpipm_ctx* c, int max_group) {
+    if (!c || max_group < -1 || max_group > 4096) return LPIPM_ERR_BAD_ARGUMENT;
+    c->lockstep_max = max_group;
+    return LPIPM_OK;
 }
 
 extern "C" int lpipm_set_batch_concurrency(lpipm_ctx* c, int nworkers) {
