@@ -299,6 +299,31 @@ class Context:
             out.append((int(st[i]), xs[i] if has_x else None, fun[i] if has_x else None, int(its[i])))
         return out
 
+    def solve_batch(self, problems, opts: "_capi.Opts"):
+        """lpipm_solve_batch over [(A, b, c, c0), ...] (any mix of shapes; equal shapes run as lockstep batches).
+        -> list of (status, x_slack | None, fun | None, iterations)"""
+        K = len(problems)
+        if K == 0:
+            return []
+        As = [_f64(p[0]) for p in problems]; bs = [_f64(p[1]) for p in problems]; cs = [_f64(p[2]) for p in problems]
+        for A, b, c in zip(As, bs, cs):
+            if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
+                raise IncompatibleInputDimensions()
+        dp = C.POINTER(C.c_double)
+        arr = lambda lst: (dp * K)(*[_p(a) for a in lst])
+        xs = [np.full(A.shape[1], np.nan) for A in As]
+        m = (C.c_uint64 * K)(*[A.shape[0] for A in As]); n = (C.c_uint64 * K)(*[A.shape[1] for A in As])
+        c0 = (C.c_double * K)(*[float(p[3]) if len(p) > 3 else 0.0 for p in problems])
+        fun = (C.c_double * K)(); its = (C.c_uint64 * K)(); st = (C.c_int32 * K)()
+        rc = _capi.lib().lpipm_solve_batch(self._h, K, m, n, arr(As), arr(bs), arr(cs), c0, C.byref(opts), arr(xs), fun, its, st)
+        if rc != _capi.OK:
+            _raise_for(rc)
+        out = []
+        for i in range(K):
+            has_x = st[i] in (_capi.OK, _capi.ITERATION_LIMIT)
+            out.append((int(st[i]), xs[i] if has_x else None, fun[i] if has_x else None, int(its[i])))
+        return out
+
     def solve_raw(self, opts: "_capi.Opts", want_log: bool = False, x_dev_ptr: int | None = None):
         """-> (status, x_slack | None, fun, iterations, log rows)"""
         x = None if x_dev_ptr is not None else np.full(self.n, np.nan)

@@ -4,6 +4,8 @@ LPs are independent, so the path shards with NO data-path collective: rank r sol
 block `shard_range(count, world, r)` on its own GPU (its own lpipm_ctx / stream), and the batch ends
 with exactly ONE collective -- an all-gather (RCCL over xGMI when the backend is "nccl") of a packed
 [shard_max, n_max + 3] block per rank holding x / tau, fun, iterations and status of each LP.
+On the GPU the shard goes to lpipm_solve_batch in one call: LPs of equal shape advance as lockstep
+batches (one kernel launch covers all of them), odd shapes one at a time.
 One process per GPU, `torch.distributed` for the plumbing; nothing here computes on the CPU.
 `solve_fn` exists so that the sharding / packing / gather logic can be unit-tested on CPU ranks
 (gloo) with an injected solver; the default is the HIP path and it fails loudly without a GPU.
@@ -22,20 +24,12 @@ def shard_range(count: int, world: int, rank: int) -> range:
     return range(lo, lo + base + (1 if rank < extra else 0))
 
 
-def _hip_solve_fn(ctx, opts):
-    def solve(A, b, c, c0, x_out_row):
-        ctx.upload_arrays(A, b, c, c0)
-        # x / tau goes straight into the packed device row (no host round trip for the solution)
-        rc, _, fun, it, _ = ctx.solve_raw(opts, x_dev_ptr=x_out_row.data_ptr())
-        return rc, None, fun, it
-    return solve
-
 
 def solve_batch_sharded(problems, opts=None, ctx=None, group=None, device=None, solve_fn=None):
     """problems: sequence of (A, b, c, c0) -- every rank passes the same list (or at least its shard
     at the right indices).  Returns, on EVERY rank, a list of dicts {status, x_slack, fun, iterations}
-    in problem order.  `solve_fn(A, b, c, c0, x_out_row) -> (status, x | None, fun, iterations)` may
-    write x into x_out_row itself (device path) or return it (test path)."""
+    in problem order.  `solve_fn(A, b, c, c0, None) -> (status, x | None, fun, iterations)` replaces the
+    library call in the CPU-rank tests."""
     import torch
     import torch.distributed as dist
 
@@ -45,25 +39,25 @@ def solve_batch_sharded(problems, opts=None, ctx=None, group=None, device=None, 
     mine = shard_range(count, world, rank)
     shard_max = -(-count // world) if count else 0
     n_max = max((np.asarray(p[2]).shape[0] for p in problems), default=0)
-    if solve_fn is None:
+    shard_results = None
+    if solve_fn is None:                              # the product path: the whole shard in one library call
         import lp_amd
         ctx = ctx or lp_amd.default_context(device.index if device is not None and device.index is not None else 0)
         opts = opts or lp_amd.InteriorPoint.default().opts()
-        solve_fn = _hip_solve_fn(ctx, opts)
+        shard_results = ctx.solve_batch([problems[i] for i in mine], opts)
         device = device or torch.device("cuda", ctx.device)
     device = device or torch.device("cpu")
-    packed = torch.zeros((max(shard_max, 1), n_max + 3), dtype=torch.float64, device=device)
-    packed[:, n_max + 2] = -1.0                       # status -1: padding slot, no LP here
+    host = np.zeros((max(shard_max, 1), n_max + 3))
+    host[:, n_max + 2] = -1.0                         # status -1: padding slot, no LP here
     for slot, i in enumerate(mine):
         A, b, c, c0 = problems[i]
         n = np.asarray(c).shape[0]
-        rc, x, fun, it = solve_fn(A, b, c, c0, packed[slot])
+        rc, x, fun, it = shard_results[slot] if shard_results is not None else solve_fn(A, b, c, c0, None)
         if x is not None:
-            packed[slot, :n] = torch.as_tensor(np.asarray(x, dtype=np.float64)).to(device)
+            host[slot, :n] = np.asarray(x, dtype=np.float64)
         ok = rc in (_capi.OK, _capi.ITERATION_LIMIT)
-        tail = torch.tensor([fun if ok and fun is not None else float("nan"), float(it), float(rc)],
-                            dtype=torch.float64)
-        packed[slot, n_max:] = tail.to(device)
+        host[slot, n_max:] = (fun if ok and fun is not None else float("nan"), float(it), float(rc))
+    packed = torch.from_numpy(host).to(device)        # one H2D of the shard's packed block
     if world > 1:
         flat = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(flat, packed, group=group)         # the single collective of the batch
