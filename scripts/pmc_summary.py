@@ -1,0 +1,38 @@
+"""Aggregates rocprofv3 --pmc counter_collection.csv files (one pass per counter group) into the JSON summary kept
+under profiles/: per-launch averages for one kernel, HBM-side traffic with the gfx950 FETCH_SIZE correction of
+/opt/skills/guides/MI355X_MICROARCH.md, MFMA busy fraction.
+usage: pmc_summary.py <kernel substring> <m> <n> <out.json> <dir with *_counter_collection.csv> [...]"""
+import csv, glob, json, os, sys
+kern, m, n, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+vals = {}
+for d in sys.argv[5:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = {}
+        for r in csv.DictReader(open(f)):
+            if kern not in r["Kernel_Name"]:
+                continue
+            per_dispatch.setdefault((r["Counter_Name"], r["Dispatch_Id"]), 0.0)
+            per_dispatch[(r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
+        for (name, _), v in per_dispatch.items():
+            vals.setdefault(name, []).append(v)
+avg = {k: sum(v) / len(v) for k, v in vals.items()}
+res = {"kernel": f"{kern} (A.diag(x/z).A^T, m={m} n={n}, lower 128x128 tiles)",
+       "command": "rocprofv3 --pmc <COUNTERS> --output-format csv -- python3 scripts/prof_c3.py   (one pass per counter group)",
+       "launches_averaged": {k: len(v) for k, v in vals.items()}}
+res.update({k + ("_KiB_raw" if k in ("FETCH_SIZE", "WRITE_SIZE") else ""): v for k, v in avg.items()})
+if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+    res["fetch_correction"] = ("x2: on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane coalesced loads "
+                               "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact")
+    res["traffic_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
+    res["algorithmic_bytes_per_launch"] = 8 * m * n + 4 * m * m
+    res["note"] = ("FETCH_SIZE counts L2->fabric requests; Infinity-Cache (256 MiB) hits are included, so this is an upper "
+                   "bound on HBM bytes.  Floor for this tiling (8 L2s, one 8x8 super-block of tiles per XCD at a time): "
+                   "6 off-diagonal super-blocks x 16 panels + 4 diagonal x 8 panels of 8.4 MB = 1.07 GB + 0.13 GB of C")
+if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
+    res["mfma_busy_fraction"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    res["mfma_busy_fraction_def"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 [cycles the kernel ran, per XCD] * 1024 SIMDs); "
+                                     "64 busy cycles per v_mfma_f64_16x16x4_f64")
+if "SQ_INSTS_VALU_MFMA_MOPS_F64" in avg:
+    res["mfma_flops_counted"] = avg["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
