@@ -161,15 +161,17 @@ int lpipm_upload_lockstep(lpipm_ctx* ctx, uint64_t count, uint64_t m, uint64_t n
                           const double* const* b, const double* const* c, const double* c0 /* nullable */);
 int lpipm_solve_lockstep(lpipm_ctx* ctx, const lpipm_opts* opts, double* const* x_slack_out, double* fun_out,
                          uint64_t* iterations_out, int32_t* status_out);
-/* lpipm_solve_batch groups members of equal shape into lockstep batches: max_group -1 = auto (default, up to 64
- * per group within the memory budget), 0 = never, > 0 = largest group. */
+/* lpipm_solve_batch groups members of equal shape into lockstep batches: max_group -1 = auto (default: chunks
+ * of up to 32 within the memory budget, the upload of one chunk overlapping the solve of the previous one), 0 = never, > 0 = largest group. */
 int lpipm_set_batch_lockstep(lpipm_ctx* ctx, int max_group);
 
 /* Number of LPs of a batch in flight at once on the device (0 = auto, the default: 8 for members up
  * to m = 2048, else 2; 1 = strictly one after the other).  Members of a batch are independent, each in-flight member has its own stream and buffers. */
 int lpipm_set_batch_concurrency(lpipm_ctx* ctx, int nworkers);
 
-/* Profiling switch (off by default) and the per-phase device times of the last solve. */
+/* Profiling switch (off by default) and the per-phase device times of the last solve: HIP events on the
+ * context's own stream.  on = 1: every phase (~14 events per iteration); on = 2: only the A.D.A^T launches
+ * (2 events per iteration; the other phases are lumped into vec_ms). */
 int lpipm_set_profiling(lpipm_ctx* ctx, int on);
 int lpipm_get_phase_times(const lpipm_ctx* ctx, lpipm_phase_times* out);
 

@@ -342,8 +342,9 @@ class Context:
                 rows.append((r.alpha, r.rho_p, r.rho_d, r.rho_A, r.rho_g, r.rho_mu, r.obj))
         return rc, x, fun.value, int(it.value), rows
 
-    def set_profiling(self, on: bool):
-        _capi.lib().lpipm_set_profiling(self._h, 1 if on else 0)
+    def set_profiling(self, on):
+        """False/0 off, True/1 every phase, 2 only the A.D.A^T launches (2 events per iteration)."""
+        _capi.lib().lpipm_set_profiling(self._h, int(on))
 
     def phase_times(self) -> dict:
         t = _capi.PhaseTimes()

@@ -55,7 +55,7 @@ __device__ __forceinline__ double fold_min(const double* red, int slot, int nblk
 
 // LP blockIdx.z of a lockstep batch.  `check_done`: kernels of the iteration skip an LP that has finished.
 __device__ __forceinline__ bool vbatch(VecArgs& a, bool check_done) {
-    const BatchK bk{a.bstride, check_done ? a.done : nullptr};
+    const BatchK bk{a.bstride, check_done ? a.done_chk : nullptr, 0};
     if (batch_done(bk)) return false;
     if (blockIdx.z == 0) return true;
     a.b = batch_ptr(a.b, bk); a.c = batch_ptr(a.c, bk);
@@ -67,6 +67,7 @@ __device__ __forceinline__ bool vbatch(VecArgs& a, bool check_done) {
     a.Ax = batch_ptr(a.Ax, bk); a.W = batch_ptr(a.W, bk); a.R = batch_ptr(a.R, bk); a.ATpart = batch_ptr(a.ATpart, bk);
     a.S = batch_ptr(a.S, bk); a.red = batch_ptr(a.red, bk); a.status = batch_ptr(a.status, bk);
     a.potrf_info = batch_ptr(a.potrf_info, bk); a.flags = batch_ptr(a.flags, bk); a.done = batch_ptr(a.done, bk);
+    a.done_chk = batch_ptr(a.done_chk, bk);
     return true;
 }
 
@@ -402,7 +403,7 @@ __global__ void k_step_scalars(VecArgs a, int ip) {
 // x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
 __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
     if (!vbatch(a, false)) return;
-    xout = batch_ptr(xout, BatchK{a.bstride, nullptr});
+    xout = batch_ptr(xout, BatchK{a.bstride, nullptr, 0});
     const int stride = gridDim.x * 256;
     const double tau = a.S[S_TAU];
     double acc[1] = {0};

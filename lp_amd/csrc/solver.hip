@@ -49,6 +49,8 @@ struct lpipm_ctx {
     size_t arena_bytes = 0, bstride = 0;
     int B = 1;
     Batch bt;                    // what the solve path hands to every launcher (count, stride, done flags)
+    Batch bt_head;               // same with the done test always on: the speculatively enqueued head of an iteration
+    hipEvent_t ev_status = nullptr;   // recorded behind the status copy of an iteration
     std::vector<void*> kallocs;  // buffers of the stand-alone kernel entry points
     // problem + state + work
     FactorPlan plan, kplan;
@@ -65,7 +67,7 @@ struct lpipm_ctx {
     int kmp = 0;
     bool kchol_valid = false;
     // profiling
-    bool profiling = false;
+    int profiling = 0;           // 0 off, 1 every phase, 2 only the A.D.A^T launches (2 events per iteration)
     std::vector<hipEvent_t> events;
     std::vector<int> mark_tags;
     size_t nmarks = 0;
@@ -79,7 +81,8 @@ struct lpipm_ctx {
     // captured iteration (hipGraph): one executable graph per (ip, options) key, valid while the buffers live
     struct IterGraph { int ip; double alpha0, tol; hipGraphExec_t exec; };
     std::vector<IterGraph> graphs;
-    int use_graph = -1;          // -1: decide from the environment / size at first use
+    int use_graph = -1;          // -1: decide from the environment at first use
+    bool no_speculate = false;
     // n-split mode (one LP split by columns over ranks; BASELINE config C5): the collective is the caller's
     bool colsplit = false;
     int rank = 0, world = 1;
@@ -128,8 +131,8 @@ static int dalloc(std::vector<void*>& list, std::vector<size_t>* sizes, T** out,
 }
 #define LP_TRY(expr) do { int rc__ = (expr); if (rc__ != LPIPM_OK) return rc__; } while (0)
 
-static void prof_mark(lpipm_ctx* c, int tag) {
-    if (!c->profiling) return;
+static void prof_mark(lpipm_ctx* c, int tag, bool adat_bracket = false) {
+    if (!c->profiling || (c->profiling == 2 && !adat_bracket)) return;
     if (c->nmarks == c->events.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
@@ -140,15 +143,21 @@ static void prof_mark(lpipm_ctx* c, int tag) {
     (void)hipEventRecord(c->events[c->nmarks], c->st);
     ++c->nmarks;
 }
-// call after the stream has been synchronised
-static void prof_collect(lpipm_ctx* c) {
+// Adds up the intervals between the first `upto` marks (all of them by default); call when those events have
+// completed.  Later marks (the speculatively enqueued head of the next iteration) move to the front.
+static void prof_collect(lpipm_ctx* c, size_t upto = (size_t)-1) {
     if (!c->profiling) return;
-    for (size_t i = 1; i < c->nmarks; ++i) {
+    if (upto > c->nmarks) upto = c->nmarks;
+    for (size_t i = 1; i < upto; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->events[i - 1], c->events[i]) == hipSuccess)
             c->tag_ms[c->mark_tags[i]] += ms;
     }
-    c->nmarks = 0;
+    for (size_t i = upto; i < c->nmarks; ++i) {
+        std::swap(c->events[i - upto], c->events[i]);
+        c->mark_tags[i - upto] = c->mark_tags[i];
+    }
+    c->nmarks -= upto;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +231,8 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void**)&c->status_host, sizeof(StatusRec)) != hipSuccess ||
-        hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess) {
+        hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming) != hipSuccess) {
         g_err_detail = "failed to create stream / pinned status / events";
         delete c;
         return LPIPM_ERR_HIP;
@@ -248,6 +258,7 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->ev_status) (void)hipEventDestroy(c->ev_status);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
@@ -381,7 +392,12 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     c->ns = (int)n_slack; c->nx = (int)nx;
     c->va.n = (int)n; c->va.m = (int)m;
     c->va.n_total = (long long)n; c->va.gs = nullptr; c->colsplit = false;   // lpipm_upload_nsplit overrides
-    c->bt = Batch{count, (long long)c->bstride, c->va.done};
+    // A single LP's loop ends on the host, so its kernels need not test the done word (one dependent load
+    // less at the start of ~100 short kernels) -- except the head of an iteration, which is enqueued before
+    // the host has seen the previous status.  In a batch every kernel tests it.
+    c->bt = Batch{count, (long long)c->bstride, count > 1 ? c->va.done : nullptr};
+    c->bt_head = Batch{count, (long long)c->bstride, c->va.done};
+    c->va.done_chk = c->bt.done;
     for (int i = 0; i < count; ++i) {
         const size_t off = (size_t)i * c->bstride;
         LP_HIP(hipMemcpy2DAsync((char*)c->A + off, (size_t)npa * sizeof(double), A[i], (size_t)lda * sizeof(double),
@@ -456,22 +472,35 @@ static int copy_status(lpipm_ctx* c) {
 
 // one IPM iteration: get_delta (feasible_point.rs:110-152), step length (mod.rs:216-221),
 // do_step (:222), indicators (:225)
-static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
-    VecArgs& v = c->va;
+// Head of an iteration: Dinv = x/z and the normal equations M = A.Dinv.A^T (newton_equations.rs:54-57).  It needs
+// nothing from the host, and its kernels test the LP's done word, so it may be enqueued BEFORE the host has read
+// the status of the previous iteration: the GPU goes straight from one iteration into the big kernel of the
+// next instead of idling through the read-back, and if the LP turns out to be finished the two kernels return
+// at once.
+static int enqueue_head(lpipm_ctx* c) {
     hipStream_t st = c->st;
+    VecArgs vh = c->va;
+    vh.done_chk = c->bt_head.done;
     prof_mark(c, T_VEC);
-    vec_pred_setup(v, st);
-    prof_mark(c, T_VEC);
-    XRank xr_{xrank_fn, c};
-    const XRank* xr = c->colsplit ? &xr_ : nullptr;
-    const Batch& bt = c->bt;
-    LP_HIP(run_adat(c, bt));                                               // newton_equations.rs:55-57
+    vec_pred_setup(vh, st);
+    prof_mark(c, T_VEC, true);
+    LP_HIP(run_adat(c, c->bt_head));                                       // newton_equations.rs:55-57
     if (c->colsplit && c->world > 1) {                                     // n-split: M = sum_g A_g D_g A_g^T
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
         LP_TRY(ctx_allreduce(c, c->mpack, c->mpack_count, 0));
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 1, st);
     }
-    prof_mark(c, T_ADAT);
+    prof_mark(c, T_ADAT, true);
+    return LPIPM_OK;
+}
+
+// The rest of the iteration, ending with the status record on its way to the host and ev_status behind it.
+static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
+    VecArgs& v = c->va;
+    hipStream_t st = c->st;
+    XRank xr_{xrank_fn, c};
+    const XRank* xr = c->colsplit ? &xr_ : nullptr;
+    const Batch& bt = c->bt;
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
     else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
@@ -515,7 +544,13 @@ static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
     LP_TRY(copy_status(c));
     prof_mark(c, T_VEC);
+    LP_HIP(hipEventRecord(c->ev_status, st));
     return LPIPM_OK;
+}
+
+static int enqueue_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
+    LP_TRY(enqueue_head(c));
+    return enqueue_tail(c, ip, o);
 }
 
 // The ~100 launches of one iteration replayed as one hipGraph launch: the sequence and every argument
@@ -561,7 +596,12 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     LP_HIP(hipSetDevice(c->device));
     VecArgs& v = c->va;
     hipStream_t st = c->st;
-    if (c->use_graph < 0) { const char* g = getenv("LPIPM_GRAPH"); c->use_graph = (g && g[0] == '1') ? 1 : 0; }
+    if (c->use_graph < 0) {   // measurement knobs: LPIPM_GRAPH=1 (hipGraph replay), LPIPM_SPECULATE=0 (no early head)
+        const char* g = getenv("LPIPM_GRAPH");
+        c->use_graph = (g && g[0] == '1') ? 1 : 0;
+        const char* sp = getenv("LPIPM_SPECULATE");
+        c->no_speculate = sp && sp[0] == '0';
+    }
     for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
     c->times = lpipm_phase_times{};
     c->nmarks = 0;
@@ -582,11 +622,25 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     int ip = o->ip ? 1 : 0;
     int ret = LPIPM_ITERATION_LIMIT;
     uint64_t iteration = 0;
+    // the head of iteration k+1 goes out before the status of iteration k is read (see enqueue_head); not when the
+    // iteration is replayed as a graph or contains host-side collectives
+    const bool speculate = c->use_graph != 1 && !c->colsplit && !c->no_speculate;
+    bool head_out = false;
     for (iteration = 1; iteration <= o->max_iter; ++iteration) {   // mod.rs:213
-        LP_TRY(run_iteration(c, ip, o));
+        if (!speculate) {
+            LP_TRY(run_iteration(c, ip, o));
+            LP_HIP(hipStreamSynchronize(st));
+            prof_collect(c);
+        } else {
+            if (!head_out) LP_TRY(enqueue_head(c));
+            LP_TRY(enqueue_tail(c, ip, o));
+            const size_t marks = c->nmarks;
+            head_out = iteration < o->max_iter;
+            if (head_out) LP_TRY(enqueue_head(c));
+            LP_HIP(hipEventSynchronize(c->ev_status));
+            prof_collect(c, marks);
+        }
         ++adat_launches;
-        LP_HIP(hipStreamSynchronize(st));
-        prof_collect(c);
         const StatusRec s = *c->status_host;
         // EquationSolverType::build failure (newton_equations.rs:58-63) and the NaN check on p, q
         // (:190-194) both surface as NumericalProblem from get_delta (mod.rs:215)
@@ -665,9 +719,13 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_ou
     std::vector<int> ret((size_t)B, -1);                                     // -1: still iterating
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
+    bool head_out = false;
     for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
-        LP_TRY(enqueue_iteration(c, ip, o));
-        LP_HIP(hipStreamSynchronize(st));
+        if (!head_out) LP_TRY(enqueue_head(c));
+        LP_TRY(enqueue_tail(c, ip, o));
+        head_out = iteration < o->max_iter;
+        if (head_out) LP_TRY(enqueue_head(c));       // next iteration's A.D.A^T, before this one's status is read
+        LP_HIP(hipEventSynchronize(c->ev_status));
         ip = 0;                                                              // mod.rs:223
         for (int i = 0; i < B; ++i) {
             if (ret[i] >= 0) continue;
@@ -892,7 +950,7 @@ extern "C" int lpipm_upload_nsplit(lpipm_ctx* c, uint64_t m, uint64_t n_total, u
 
 extern "C" int lpipm_set_profiling(lpipm_ctx* c, int on) {
     if (!c) return LPIPM_ERR_BAD_ARGUMENT;
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return LPIPM_OK;
 }
 extern "C" int lpipm_get_phase_times(const lpipm_ctx* c, lpipm_phase_times* out) {

@@ -42,6 +42,7 @@ struct VecArgs {
     int32_t *potrf_info;
     int *flags;
     int *done;        // set by k_scalar_indicators when the LP has reached a final status; cleared by k_blind_start
+    const int *done_chk;  // what the kernels of the iteration test before doing anything (nullptr: no test)
     int bcount;       // lockstep batch: LPs per launch (gridDim.z); every pointer above is LP 0's,
     long long bstride;//   LP z's is bstride bytes * z further
 };

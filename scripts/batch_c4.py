@@ -26,14 +26,14 @@ def report(tag, dt, rc=0):
 L.lpipm_set_batch_lockstep(ctx._h, 0)
 for conc in (1, 8):
     L.lpipm_set_batch_concurrency(ctx._h, conc)
-    for rep in range(2):
+    for rep in range(4):
         t = time.perf_counter()
         rc = L.lpipm_solve_batch(ctx._h, K, m, n, arr(As), arr(bs), arr(cs), None, C.byref(o), arr(xs), fun, its, st)
         dt = time.perf_counter() - t
     report(f"(a) one by one, concurrency {conc}", dt, rc)
 for grp in (-1, 8, 16, 32):
     L.lpipm_set_batch_lockstep(ctx._h, grp)
-    for rep in range(2):
+    for rep in range(4):
         t = time.perf_counter()
         rc = L.lpipm_solve_batch(ctx._h, K, m, n, arr(As), arr(bs), arr(cs), None, C.byref(o), arr(xs), fun, its, st)
         dt = time.perf_counter() - t

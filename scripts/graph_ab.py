@@ -1,4 +1,5 @@
-"""A/B: iteration replay through a hipGraph (LPIPM_GRAPH=1) vs direct launches, several sizes."""
+"""A/B/C on one box: plain launches with a host round trip per iteration; the iteration replayed as a hipGraph
+(LPIPM_GRAPH=1); plain launches with the head of the next iteration enqueued before the status read (default)."""
 import os, sys, time, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -13,9 +14,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         t = time.perf_counter()
         for _ in range(reps): rc, x, fun, it, _ = ctx.solve_raw(o)
         dt = (time.perf_counter() - t) / reps
-        print(f"graph={os.environ.get('LPIPM_GRAPH','0')} {m}x{n}: rc={rc} it={it} {dt*1e3:.3f} ms/solve {it/dt:.1f} it/s err={abs(x-xs).max():.2e}", flush=True)
+        print(f"graph={os.environ.get('LPIPM_GRAPH','0')} early-head={os.environ.get('LPIPM_SPECULATE','1')} {m}x{n}: rc={rc} it={it} {dt*1e3:.3f} ms/solve {it/dt:.1f} it/s err={abs(x-xs).max():.2e}", flush=True)
         ctx.close()
 else:
-    for g in ("0", "1"):
-        env = dict(os.environ, LPIPM_GRAPH=g)
+    for g, sp in (("0", "0"), ("1", "1"), ("0", "1")):
+        env = dict(os.environ, LPIPM_GRAPH=g, LPIPM_SPECULATE=sp)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
