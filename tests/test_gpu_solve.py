@@ -363,3 +363,28 @@ def test_graph_replay_is_bit_identical(built, monkeypatch):
     assert r0[0] == r1[0] == r2[0] == r3[0] == 0 and r0[3] == r1[3] == r2[3]
     assert np.array_equal(r0[1], r1[1]) and np.array_equal(r0[1], r2[1]) and r0[4] == r1[4] == r2[4]
     assert np.abs(r3[1] - r0[1]).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", ["dup_rows", "dependent_row", "zero_row"])
+def test_rank_deficient_constraints_are_a_numerical_problem(ctx, case):
+    """Linearly dependent rows make A.D.A^T singular: the reference's Cholesky fails and `solve` returns
+    NumericalProblem (newton_equations.rs:58-63 -> mod.rs:215); the oracle does so in iteration 1.  On the GPU the
+    zero pivot is detected by the diagonal-block kernel (or, if rounding leaves it a hair positive, by the NaN check
+    one iteration later)."""
+    import lp_amd
+    from lp_amd import _capi, synth
+    from oracle import capi as oracle
+    A, b, c, _ = synth.planted_lp(1, 200, 520)
+    if case == "dup_rows":
+        A2, b2 = np.vstack([A, A[:3]]), np.concatenate([b, b[:3]])
+    elif case == "dependent_row":
+        A2, b2 = np.vstack([A, A[0:1] + A[1:2]]), np.concatenate([b, b[0:1] + b[1:2]])
+    else:
+        A2, b2 = np.vstack([A, np.zeros((1, 520))]), np.concatenate([b, [0.0]])
+    ref = oracle.solve(A2, b2, c)
+    assert ref["status"] == _capi.NUMERICAL_PROBLEM
+    ctx.upload_arrays(A2, b2, c)
+    rc, x, fun, it, _ = ctx.solve_raw(lp_amd.InteriorPoint.default().opts())
+    assert rc == _capi.NUMERICAL_PROBLEM and it <= ref["iterations"] + 1
+    with pytest.raises(lp_amd.NumericalProblem):
+        lp_amd.InteriorPoint.default().solve(lp_amd.Problem.target(c).eq(A2, b2).build())
