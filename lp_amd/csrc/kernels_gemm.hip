@@ -24,6 +24,7 @@
 //   * workgroups are renumbered so that the 64 that share an XCD (and its L2) work on one
 //     8x8 super-block of tiles: 16 row panels of A feed 64 tiles.
 #include "lpipm_internal.hpp"
+#include <cstdlib>
 
 namespace lpipm {
 
@@ -145,7 +146,8 @@ __device__ __forceinline__ void tile_mainloop(double (*ldsA)[32 * MTM][LDS_STRID
 // in SGPRs.  cb = &C[tile_row0 + wr*16*MTM + fq][tile_col0 + wc*16*MTN + fr].
 template <int MTM, int MTN>
 __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (&acc)[MTM][MTN], double alpha,
-                                           double beta, bool pad_diag, int row0, int diag_pad_from, int fr, int fq) {
+                                           double beta, bool pad_diag, int row0, int diag_pad_from, int fr, int fq,
+                                           int diag_delta = 0) {   // (wave's column offset - row offset) inside the tile
     if (beta != 0.0) {   // wave-uniform.  All C values of a 16-row block are requested before any is used.
 #pragma unroll
         for (int mi = 0; mi < MTM; ++mi) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (
 #pragma unroll
             for (int nj = 0; nj < MTN; ++nj) {
                 double v = alpha * acc[mi][nj][r];
-                if (pad_diag && mi == nj && fq + 4 * r == fr && row0 + mi * 16 + 4 * r >= diag_pad_from) v = 1.0;
+                if (pad_diag && (mi - nj) * 16 + fq + 4 * r - fr == diag_delta && row0 + mi * 16 + 4 * r >= diag_pad_from) v = 1.0;
                 rp[nj * 16] = v;
             }
         }
@@ -249,6 +251,131 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p0)
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nj = 0; nj < 4; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
+        }
+        it += ke - kb;
+        first = false;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 8-wave form of the same 128x128 workgroup tile: 512 threads = 2x4 waves of 64x32 (4x2 MFMA tiles, 32 fp64
+// accumulators per lane), <= 128 VGPRs, so TWO such workgroups = 4 waves per SIMD are resident per CU.
+// Why: with 2 waves per SIMD a wave's non-MFMA phase of a k-tile (issue the prefetch, ds_read the fragments,
+// scale + ds_write the next k-tile, barrier: ~4000 cycles under contention, s_memtime stamps) is as long as its
+// partner's MFMA phase (64 x 64 cycles), so the two can only just cover each other (measured 87 % MFMA-busy);
+// with 4 waves per SIMD each wave issues 32 MFMAs per k-tile and has three partners' 6144 cycles of cover.
+// Same operands, LDS image, stream-K split, slabs and fix-up as gemm_nt_streamk_kernel.
+template <bool SCALE>
+__device__ __forceinline__ void tile_mainloop_w8(double (*ldsA)[TILE][LDS_STRIDE], double (*ldsB)[TILE][LDS_STRIDE],
+                                                 const double* __restrict__ Pp, long long ldp,
+                                                 const double* __restrict__ Qp, long long ldq,
+                                                 const double* __restrict__ s, int kb, int ke, d4 (&acc)[4][2],
+                                                 int srow, int scol, int wr, int wc, int fr, int fq) {
+    d2 sa[2], sb[2], sv = (d2){1.0, 1.0};
+    auto gload = [&](int kt) {
+        const long long ko = (long long)kt * BK;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) sa[r] = *(const d2*)(Pp + (long long)(64 * r) * ldp + ko);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) sb[r] = *(const d2*)(Qp + (long long)(64 * r) * ldq + ko);
+        if (SCALE) sv = *(const d2*)(s + ko + scol);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) *(d2*)&ldsA[buf][srow + 64 * r][scol] = sa[r];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) *(d2*)&ldsB[buf][srow + 64 * r][scol] = SCALE ? sb[r] * sv : sb[r];
+    };
+    gload(kb);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kb; kt < ke; ++kt) {
+        const bool more = kt + 1 < ke;
+        if (more) gload(kt + 1);
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            d2 a[4], b[2];
+            if (round == 0) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *(const d2*)&ldsA[cur][wr * 64 + mi * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) b[nj] = *(const d2*)&ldsB[cur][wc * 32 + nj * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(2);   // the short non-MFMA phase goes first: it is what the partners wait for
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <bool SCALE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_streamk_w8_kernel(const GemmK p0) {
+    if (batch_done(p0.bk)) return;
+    const GemmK p = batch_shift(p0);
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves: 64 rows x 32 columns each
+    const int fr = lane & 15, fq = lane >> 4;
+    const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
+    const int g = p.bk.xcd_major ? (int)blockIdx.y : xcd_remap(blockIdx.x, gridDim.x);
+    const int KT = p.KT;
+    const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
+    auto zero = [](d4 (&acc)[4][2]) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+    };
+    auto store_tile = [&](const d4 (&acc)[4][2], int ti, int tj) {
+        double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 32 + fr);
+        tile_store<4, 2>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj, ti * TILE + wr * 64 + fq,
+                         p.diag_pad_from, fr, fq, wc * 32 - wr * 64);
+    };
+    for (int tile = g; tile < ntiles_dp; tile += p.nwg) {
+        int ti, tj;
+        tile_coords(p, tile, ti, tj);
+        d4 acc[4][2];
+        zero(acc);
+        tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
+                                p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, 0, KT, acc, srow, scol, wr,
+                                wc, fr, fq);
+        store_tile(acc, ti, tj);
+    }
+    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
+    long long it = wg_begin(g, total, p.nwg);
+    const long long end = wg_begin(g + 1, total, p.nwg);
+    bool first = true;
+    while (it < end) {
+        const int rt = (int)(it / KT);
+        const int kb = (int)(it - (long long)rt * KT);
+        const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
+        int ti, tj;
+        tile_coords(p, ntiles_dp + rt, ti, tj);
+        d4 acc[4][2];
+        zero(acc);
+        tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
+                                p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow, scol, wr,
+                                wc, fr, fq);
+        if (kb == 0 && ke == KT) {
+            store_tile(acc, ti, tj);
+        } else {
+            double* sb0 = p.ws + ((long long)(2 * g + (first ? 0 : 1))) * (TILE * TILE) + (wr * 64 + fq) * TILE + wc * 32 + fr;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
         }
         it += ke - kb;
         first = false;
@@ -423,8 +550,10 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     const bool xm = B >= 8 && B % 8 == 0;
     k.bk.xcd_major = xm ? 1 : 0;
     const dim3 grid = xm ? dim3(8, a.nwg, B / 8) : dim3(a.nwg, 1, B);
-    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
-    else     hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, grid, dim3(256), 0, st, k);
+    static const bool w4 = getenv("LPIPM_ADAT_W4") != nullptr;
+    if (a.s && !w4) hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<true>, grid, dim3(512), 0, st, k);
+    else if (a.s)   hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
+    else            hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, grid, dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // remainder tiles: a split exists unless every workgroup boundary falls on a tile boundary
