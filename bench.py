@@ -156,7 +156,7 @@ def main():
                                    f"(seed = rank), reference default options, A resident in HBM",
                        "m": m, "n": n, "iterations_per_solve": iters_local / args.steps,
                        "max_abs_err_vs_planted_optimum": err},
-            "roofline": {"kernel": "gemm_nt_streamk_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
+            "roofline": {"kernel": "gemm_nt_streamk_w8_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
                                    "v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
