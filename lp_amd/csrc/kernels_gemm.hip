@@ -550,9 +550,10 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     const bool xm = B >= 8 && B % 8 == 0;
     k.bk.xcd_major = xm ? 1 : 0;
     const dim3 grid = xm ? dim3(8, a.nwg, B / 8) : dim3(a.nwg, 1, B);
-    static const bool w4 = getenv("LPIPM_ADAT_W4") != nullptr;
+    static const bool w4 = getenv("LPIPM_ADAT_W4") != nullptr;   // measurement knob: the 4-wave form (scripts/adat_ab.py)
     if (a.s && !w4) hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<true>, grid, dim3(512), 0, st, k);
     else if (a.s)   hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
+    else if (!w4)   hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<false>, grid, dim3(512), 0, st, k);
     else            hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, grid, dim3(256), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
