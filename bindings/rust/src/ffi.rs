@@ -2,7 +2,7 @@
 //! The crate denies `unsafe_code` (.cargo/config.toml:6); this module is the one scoped exception.
 #![allow(unsafe_code, non_camel_case_types)]
 
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
 pub struct lpipm_ctx {
@@ -59,4 +59,32 @@ extern "C" {
     ) -> c_int;
     pub fn lpipm_strerror(status: c_int) -> *const c_char;
     pub fn lpipm_last_error_detail() -> *const c_char;
+
+    // A batch of independent LPs on one device (BASELINE config 4): members of equal shape advance as
+    // lockstep batches, one kernel launch covering all of them.
+    pub fn lpipm_solve_batch(
+        ctx: *mut lpipm_ctx, count: u64, m: *const u64, n: *const u64, a: *const *const f64,
+        b: *const *const f64, c: *const *const f64, c0: *const f64, opts: *const lpipm_opts,
+        x_slack_out: *const *mut f64, fun_out: *mut f64, iterations_out: *mut u64, status_out: *mut i32,
+    ) -> c_int;
+    pub fn lpipm_upload_lockstep(
+        ctx: *mut lpipm_ctx, count: u64, m: u64, n: u64, a: *const *const f64, b: *const *const f64,
+        c: *const *const f64, c0: *const f64,
+    ) -> c_int;
+    pub fn lpipm_solve_lockstep(
+        ctx: *mut lpipm_ctx, opts: *const lpipm_opts, x_slack_out: *const *mut f64, fun_out: *mut f64,
+        iterations_out: *mut u64, status_out: *mut i32,
+    ) -> c_int;
+
+    // One LP split by columns over ranks (BASELINE config 5): the caller supplies the all-reduce
+    // (e.g. ncclAllReduce on `stream`); op 0 = sum, 1 = min.
+    pub fn lpipm_set_collective(
+        ctx: *mut lpipm_ctx, rank: c_int, world: c_int,
+        f: Option<unsafe extern "C" fn(user: *mut c_void, dev_ptr: *mut c_void, count: u64, op: c_int, stream: *mut c_void) -> c_int>,
+        user: *mut c_void,
+    ) -> c_int;
+    pub fn lpipm_upload_nsplit(
+        ctx: *mut lpipm_ctx, m: u64, n_total: u64, n_local: u64, a_local: *const f64, lda: u64,
+        b: *const f64, c_local: *const f64, c0: f64,
+    ) -> c_int;
 }
