@@ -485,6 +485,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_grouped_kernel(const GemmTileD
     tile_store<4, 4>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
 }
 
+// The same with 64x64 output tiles (4 resident workgroups per CU): a merge stage of one LP is a few dozen
+// 128x128 tiles on 512 slots and each tile's k-loop is pure latency, so quartering the tiles quarters the
+// stage's duration; the triangular k-ranges are also tighter at 64 granularity.
+__global__ __launch_bounds__(256, 4) void gemm_nt_grouped64_kernel(const GemmTileDesc* __restrict__ descs, BatchK bk) {
+    if (batch_done(bk)) return;
+    __shared__ __attribute__((aligned(16))) double ldsA[2][64][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][64][LDS_STRIDE];
+    TILE_THREAD_IDS
+    GemmTileDesc d = descs[blockIdx.x];
+    d.P = batch_ptr(d.P, bk); d.Q = batch_ptr(d.Q, bk); d.C = batch_ptr(d.C, bk);
+    d4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_mainloop<false, 2, 2>(ldsA, ldsB, d.P + (long long)srow * d.ldp + scol, d.ldp, d.Q + (long long)srow * d.ldq + scol,
+                               d.ldq, nullptr, d.kt_begin, d.kt_end, acc, srow, scol, wr, wc, fr, fq);
+    double* cb = d.C + (long long)(wr * 32 + fq) * d.ldc + (wc * 32 + fr);
+    tile_store<2, 2>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
+}
+
 // Adds the partial slabs of every stream-K (remainder) tile whose k-range was split, in workgroup
 // order.  grid = remainder tiles x FIX_SPLIT: a tile can have dozens of slabs, so its 16K elements are
 // spread over FIX_SPLIT workgroups (8 rows each) to keep this pass off the critical path.
@@ -570,9 +591,10 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     return e;
 }
 
-hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt) {
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt, int edge) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
+    if (edge == 64) hipLaunchKernelGGL(gemm_nt_grouped64_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
+    else            hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
     return hipGetLastError();
 }
 

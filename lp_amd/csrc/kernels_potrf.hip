@@ -423,7 +423,7 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
     // inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
     // grouped launch of stage A (T^T = Inv11^T.L21^T) then stage B (Inv21 = -Inv22.T and its transpose)
     for (const auto& stg : plan.stages) {
-        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st, bt);
+        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st, bt, plan.merge_edge);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

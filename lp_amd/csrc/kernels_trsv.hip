@@ -55,10 +55,12 @@ int plan_merges(int sb, int lo, int hi, std::vector<Merge>& out, size_t& tcursor
 }  // namespace
 
 hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build,
-                              hipStream_t st, int super_w) {
+                              hipStream_t st, int super_w, int merge_edge) {
     factor_plan_destroy(plan);
     plan.mp = mp;
     plan.super_w = super_w;
+    plan.merge_edge = merge_edge == 64 ? 64 : 128;
+    const int E = plan.merge_edge, SUB = NB / E, EK = E / BK;   // sub-tiles per 128-block edge, k-tiles per sub-tile edge
     hipError_t e;
     for (int r0 = 0; r0 < mp; r0 += super_w) {
         SuperBlock s{};
@@ -90,16 +92,16 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
             if (m.level != lvl) continue;
             const SuperBlock& s = plan.sbs[m.sb];
             const int n1 = m.mid - m.lo, n2 = m.hi - m.mid;
-            for (int tj = 0; tj < n1; ++tj)
-                for (int ti = 0; ti < n2; ++ti) {
+            for (int tj = 0; tj < n1 * SUB; ++tj)           // sub-tile indices: rows of T^T, columns of T^T
+                for (int ti = 0; ti < n2 * SUB; ++ti) {
                     GemmTileDesc d{};
-                    d.P = s.invT + (size_t)((m.lo + tj) * NB) * s.size + m.lo * NB;
+                    d.P = s.invT + (size_t)(m.lo * NB + tj * E) * s.size + m.lo * NB;
                     d.ldp = s.size;
-                    d.Q = L + (size_t)(s.row0 + (m.mid + ti) * NB) * ld + s.row0 + m.lo * NB;
+                    d.Q = L + (size_t)(s.row0 + m.mid * NB + ti * E) * ld + s.row0 + m.lo * NB;
                     d.ldq = (int)ld;
-                    d.C = tws + m.toff + (size_t)(tj * NB) * (n2 * NB) + ti * NB;
+                    d.C = tws + m.toff + (size_t)(tj * E) * (n2 * NB) + ti * E;
                     d.ldc = n2 * NB;
-                    d.kt_begin = tj * KPB;
+                    d.kt_begin = tj * EK;                   // Inv11^T is upper triangular: k >= row
                     d.kt_end = n1 * KPB;
                     d.alpha = 1.0;
                     descs.push_back(d);
@@ -114,28 +116,28 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
             const SuperBlock& s = plan.sbs[m.sb];
             const int n1 = m.mid - m.lo, n2 = m.hi - m.mid;
             double* TT = tws + m.toff;
-            for (int ti = 0; ti < n2; ++ti)
-                for (int tj = 0; tj < n1; ++tj) {
+            for (int ti = 0; ti < n2 * SUB; ++ti)
+                for (int tj = 0; tj < n1 * SUB; ++tj) {
                     GemmTileDesc d{};   // Inv21(ti,tj) = -sum_k Inv22[ti][k] T^T[tj][k]
-                    d.P = s.inv + (size_t)((m.mid + ti) * NB) * s.size + m.mid * NB;
+                    d.P = s.inv + (size_t)(m.mid * NB + ti * E) * s.size + m.mid * NB;
                     d.ldp = s.size;
-                    d.Q = TT + (size_t)(tj * NB) * (n2 * NB);
+                    d.Q = TT + (size_t)(tj * E) * (n2 * NB);
                     d.ldq = n2 * NB;
-                    d.C = s.inv + (size_t)((m.mid + ti) * NB) * s.size + (m.lo + tj) * NB;
+                    d.C = s.inv + (size_t)(m.mid * NB + ti * E) * s.size + (m.lo * NB + tj * E);
                     d.ldc = s.size;
                     d.kt_begin = 0;
-                    d.kt_end = (ti + 1) * KPB;
+                    d.kt_end = (ti + 1) * EK;               // Inv22 is lower triangular: k <= row
                     d.alpha = -1.0;
                     descs.push_back(d);
                     GemmTileDesc t{};   // Inv21^T(tj,ti) = -sum_k T^T[tj][k] Inv22[ti][k]
-                    t.P = TT + (size_t)(tj * NB) * (n2 * NB);
+                    t.P = TT + (size_t)(tj * E) * (n2 * NB);
                     t.ldp = n2 * NB;
-                    t.Q = s.inv + (size_t)((m.mid + ti) * NB) * s.size + m.mid * NB;
+                    t.Q = s.inv + (size_t)(m.mid * NB + ti * E) * s.size + m.mid * NB;
                     t.ldq = s.size;
-                    t.C = s.invT + (size_t)((m.lo + tj) * NB) * s.size + (m.mid + ti) * NB;
+                    t.C = s.invT + (size_t)(m.lo * NB + tj * E) * s.size + (m.mid * NB + ti * E);
                     t.ldc = s.size;
                     t.kt_begin = 0;
-                    t.kt_end = (ti + 1) * KPB;
+                    t.kt_end = (ti + 1) * EK;
                     t.alpha = -1.0;
                     descs.push_back(t);
                 }

@@ -100,7 +100,7 @@ struct GemmArgs {
 // Launches the main kernel and, when the k-range of a tile is split over workgroups, the
 // deterministic fix-up pass.  ws must hold 2*nwg slabs when nwg != ntiles.
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st);
-// One 128x128 output tile of a grouped launch: C = alpha * P[0:128, kb:ke) . Q[0:128, kb:ke)^T
+// One output tile (128x128, or 64x64 with edge = 64) of a grouped launch: C = alpha * P[0:E, kb:ke) . Q[0:E, kb:ke)^T
 // (k-range in units of BK), each tile with its own operands.
 struct GemmTileDesc {
     const double* P; const double* Q; double* C;
@@ -109,7 +109,8 @@ struct GemmTileDesc {
     double alpha;
 };
 // descs_dev holds LP 0's pointers; LP z of a batch shifts P, Q, C by z*stride.
-hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt = Batch{});
+hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt = Batch{},
+                               int edge = 128);
 // Workgroup count the stream-K ADA^T launch wants for ntiles x KT work.
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 
@@ -125,6 +126,7 @@ struct SuperBlock {
 };
 struct FactorPlan {
     int mp = 0;
+    int merge_edge = 128;    // output tile edge of the merge GEMMs (64: latency-bound single LP, 128: flop-bound batch)
     int super_w = SUPER;     // width of the diagonal super-blocks whose inverses are formed: wider = fewer, fully
                              // parallel solve steps, but the merge GEMMs cost flops (a batch that already fills
                              // the chip prefers 512)
@@ -141,7 +143,7 @@ struct FactorPlan {
 // the never-written halves of the triangular inverses are read as zeros) and, when `build`, uploads the
 // merge descriptors.  build == false: sizing pass over a measuring arena, nothing is allocated.
 hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int mp, Arena& arena, bool build, hipStream_t st,
-                              int super_w = SUPER);
+                              int super_w = SUPER, int merge_edge = 128);
 void factor_plan_destroy(FactorPlan& plan);
 
 // ---------------------------------------------------------------- Cholesky (kernels_potrf.hip)

@@ -282,6 +282,14 @@ static std::vector<int2> adat_tile_order(int nt) {
     return v;
 }
 
+// Output tile edge of the inverse-merge GEMMs: 64 (a stage of one LP is a few dozen latency-bound tiles: factorisation
+// 422 -> 358 us at m = 512, 719 -> 547 at 1024, 2556 -> 2398 at 4096; a batch that fills the chip is indifferent).
+// LPIPM_MERGE_EDGE=128 restores the 128x128 tiles (measurement knob, scripts/potrf_sizes.py).
+static int merge_edge_for(int) {
+    if (const char* e = getenv("LPIPM_MERGE_EDGE")) return atoi(e) == 128 ? 128 : 64;
+    return 64;
+}
+
 // Per-LP device state: one pass over a measuring arena sizes it, a second pass over the real one places it.
 // Every LP of a lockstep batch gets the same layout, `bstride` bytes after the previous LP's.
 static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
@@ -305,7 +313,7 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     c->M = ar.take<double>(mp * mp);
     // a batch that fills the chip is flop-bound: the last doubling level of the inverse (1024) costs more than the
     // two extra solve steps it saves
-    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, c->B >= 8 ? 512 : SUPER));
+    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, c->B >= 8 ? 512 : SUPER, merge_edge_for(c->B)));
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
@@ -1003,12 +1011,12 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->ktau, (size_t)mp, c->st));
     Arena measure;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st, SUPER, merge_edge_for(1)));
     char* kar = nullptr;
     LP_TRY(dalloc(c->kallocs, nullptr, &kar, measure.off + 256, c->st));   // zeroed
     Arena real;
     real.base = kar;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st, SUPER, merge_edge_for(1)));
     c->kmp = mp;
     return LPIPM_OK;
 }
