@@ -62,6 +62,8 @@ def main():
     if world > 1 or os.environ.get("LPIPM_BENCH_FORCE_DIST") == "1":   # the latter: rehearse the N>1 path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")          # only matter for the one-rank rehearsal:
+        os.environ.setdefault("MASTER_PORT", "29517")              # torch.distributed.run sets both
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     else:
