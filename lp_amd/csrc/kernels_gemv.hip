@@ -14,12 +14,12 @@ namespace lpipm {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int GN_ROWS_PER_WAVE = 2;
-constexpr int GN_ROWS_PER_WG   = 4 * GN_ROWS_PER_WAVE;
+// rows per wave: 2 for the passes over A (more bytes in flight per wave), 1 for short matrices (the blocks of the
+// triangular solves: 1024 rows would otherwise occupy only half of the CUs)
 
 // One wave computes GN_ROWS_PER_WAVE row dot products; np (padded row length) is a multiple of 16,
 // W is zero beyond the true n, so the 128-wide strides need a tail guard only on np.
-template <int NRHS>
+template <int NRHS, int GN_ROWS_PER_WAVE>
 __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, long long lda, int m,
                                                      int np, const double* __restrict__ W, long long ldw,
                                                      const double* add0,
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
     A = batch_ptr(A, bk); W = batch_ptr(W, bk); add0 = batch_ptr(add0, bk); add1 = batch_ptr(add1, bk);
     Y = batch_ptr(Y, bk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int GN_ROWS_PER_WG = 4 * GN_ROWS_PER_WAVE;
     const int row0 = blockIdx.x * GN_ROWS_PER_WG + wave * GN_ROWS_PER_WAVE;
     if (row0 >= m) return;
     double acc[GN_ROWS_PER_WAVE][NRHS];
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __rest
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
                          hipStream_t st, double alpha, const Batch& bt) {
-    const dim3 grid((m + GN_ROWS_PER_WG - 1) / GN_ROWS_PER_WG, 1, bt.count);
-    if (nrhs == 1)
-        hipLaunchKernelGGL(gemv_n_kernel<1>, grid, dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha, batch_k(bt));
-    else
-        hipLaunchKernelGGL(gemv_n_kernel<2>, grid, dim3(256), 0, st, A, (long long)lda, m, np, W,
-                           (long long)ldw, add0, add1, Y, (long long)ldy, alpha, batch_k(bt));
+    const int rpw = m <= 2048 ? 1 : 2;
+    const dim3 grid((m + 4 * rpw - 1) / (4 * rpw), 1, bt.count);
+#define GN_LAUNCH(NR, RPW) hipLaunchKernelGGL((gemv_n_kernel<NR, RPW>), grid, dim3(256), 0, st, A, (long long)lda, m, np, W, \
+                                              (long long)ldw, add0, add1, Y, (long long)ldy, alpha, batch_k(bt))
+    if (nrhs == 1) { if (rpw == 1) GN_LAUNCH(1, 1); else GN_LAUNCH(1, 2); }
+    else           { if (rpw == 1) GN_LAUNCH(2, 1); else GN_LAUNCH(2, 2); }
+#undef GN_LAUNCH
     return hipGetLastError();
 }
 
