@@ -131,3 +131,29 @@ def test_solve_batch_groups_same_shapes(built):
             assert st[i] == 0 and its[i] == ref["iterations"], (mode, i)
             assert np.abs(xs[i] - ref["x_slack"]).max() <= 1e-6
             assert abs(fun[i] - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
+
+
+def test_lockstep_c4_shape_properties(built):
+    """BASELINE config 4's member shape (1024x2048), 8 members in lockstep: size-independent properties of every
+    answer (primal feasibility, x >= 0, objective equal to the planted optimum's) and agreement with the planted
+    vertex and with the one-at-a-time path.  (The oracle needs ~10 s per such LP: not used here.)"""
+    import lp_amd
+    from lp_amd import synth
+    probs = [synth.planted_lp(s, 1024, 2048) for s in range(8)]     # seeds with a rounding noise floor < 1e-6
+    o = lp_amd.InteriorPoint.default().opts()
+    ctx = lp_amd.Context(0)
+    ctx.upload_lockstep([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs])
+    res = ctx.solve_lockstep(o)
+    single = lp_amd.Context(0)
+    for i, (A, b, c, xstar) in enumerate(probs):
+        st, x, fun, it = res[i]
+        assert st == 0
+        assert np.abs(A @ x - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+        assert x.min() >= -1e-12
+        assert abs(fun - c @ xstar) <= 1e-6 * max(1.0, abs(c @ xstar))
+        assert np.abs(x - xstar).max() <= 1e-6
+        single.upload_arrays(A, b, c)
+        rc, x1, f1, it1, _ = single.solve_raw(o)
+        assert rc == 0 and it1 == it and np.abs(x1 - x).max() <= 1e-6
+    single.close()
+    ctx.close()
