@@ -406,16 +406,17 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     c->bt = Batch{count, (long long)c->bstride, count > 1 ? c->va.done : nullptr};
     c->bt_head = Batch{count, (long long)c->bstride, c->va.done};
     c->va.done_chk = c->bt.done;
+    std::vector<double> c0v((size_t)count, 0.0);          // must outlive the asynchronous copies below
+    for (int i = 0; i < count; ++i) c0v[i] = c0 ? c0[i] : 0.0;
     for (int i = 0; i < count; ++i) {
         const size_t off = (size_t)i * c->bstride;
         LP_HIP(hipMemcpy2DAsync((char*)c->A + off, (size_t)npa * sizeof(double), A[i], (size_t)lda * sizeof(double),
                                 (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, st));
         LP_HIP(hipMemcpyAsync((char*)c->va.b + off, b[i], m * sizeof(double), hipMemcpyHostToDevice, st));
         LP_HIP(hipMemcpyAsync((char*)c->va.c + off, cc[i], n * sizeof(double), hipMemcpyHostToDevice, st));
-        const double c0i = c0 ? c0[i] : 0.0;
-        LP_HIP(hipMemcpyAsync((char*)(c->va.S + S_C0) + off, &c0i, sizeof(double), hipMemcpyHostToDevice, st));
-        LP_HIP(hipStreamSynchronize(st));   // c0i lives on this stack frame; pageable sources are staged anyway
+        LP_HIP(hipMemcpyAsync((char*)(c->va.S + S_C0) + off, &c0v[i], sizeof(double), hipMemcpyHostToDevice, st));
     }
+    LP_HIP(hipStreamSynchronize(st));   // the caller's arrays and c0v are free again from here
     c->has_problem = true;
     return LPIPM_OK;
 }
