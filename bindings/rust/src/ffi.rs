@@ -53,6 +53,10 @@ extern "C" {
         ctx: *mut lpipm_ctx, m: u64, n: u64, a: *const f64, lda: u64, b: *const f64, c: *const f64, c0: f64,
         n_slack: u64,
     ) -> c_int;
+    pub fn lpipm_upload_ub_eq(
+        ctx: *mut lpipm_ctx, n: u64, m_ub: u64, a_ub: *const f64, lda_ub: u64, b_ub: *const f64, m_eq: u64,
+        a_eq: *const f64, lda_eq: u64, b_eq: *const f64, c: *const f64, c0: f64,
+    ) -> c_int;
     pub fn lpipm_solve(
         ctx: *mut lpipm_ctx, opts: *const lpipm_opts, x_slack_out: *mut f64, fun_out: *mut f64,
         iterations_out: *mut u64, log: *mut lpipm_iter_row,

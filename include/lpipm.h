@@ -112,6 +112,16 @@ int lpipm_upload(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A, uint64
 int lpipm_upload_slack(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                        const double* b, const double* c, double c0, uint64_t n_slack);
 
+/* Device-side assembly of the slack form (ProblemBuilder::build, linear_program.rs:125-169, without its
+ * (m_ub+m_eq) x (n+m_ub) host matrix): the `ub` and `eq` blocks go to the device as they are -- rows of A_ub
+ * first, then rows of A_eq (linear_program.rs:145-156) -- b = [b_ub; b_eq] (:157-158), c = [c; 0] (:159-160),
+ * and the slack block [I; 0] is never formed anywhere.  Equivalent to lpipm_problem_build + lpipm_upload_slack
+ * (bit-identical solves); x_slack_out of lpipm_solve then has n + m_ub entries, slack values last.
+ * Either block may be absent (m_ub or m_eq 0, pointer NULL); both absent -> LPIPM_UNCONSTRAINED (:134-136). */
+int lpipm_upload_ub_eq(lpipm_ctx* ctx, uint64_t n, uint64_t m_ub, const double* A_ub, uint64_t lda_ub,
+                       const double* b_ub, uint64_t m_eq, const double* A_eq, uint64_t lda_eq, const double* b_eq,
+                       const double* c, double c0);
+
 /* InteriorPoint::solve_normal_form + the `fun` of solve (mod.rs:199-240, :165).
  *   x_slack_out[n] : x / tau  (mod.rs:231); ALSO filled for LPIPM_ITERATION_LIMIT (mod.rs:237-239)
  *   fun_out        : c . x_slack + c0  (linear_program.rs:61-63)

@@ -107,14 +107,25 @@ def _f64(a):
 class Problem:
     """A linear program in slack form (linear_program.rs:24-30): min c'x st A x == b, x >= 0."""
 
-    def __init__(self, A, b, c, c0, n_slack):
+    def __init__(self, A, b, c, c0, n_slack, parts=None):
         self._A, self._b, self._c, self._c0, self._n_slack = A, b, c, float(c0), int(n_slack)
+        # the `ub` / `eq` blocks the builder was given: (A_ub, b_ub, A_eq, b_eq, c).  With them the slack-form matrix
+        # is assembled on the device (lpipm_upload_ub_eq) and the host copy below exists only if A() is asked for.
+        self._parts = parts
 
     @staticmethod
     def target(c) -> "ProblemBuilder":          # linear_program.rs:37-39
         return ProblemBuilder(c)
 
     def A(self) -> np.ndarray:                   # :42-44
+        if self._A is None:                      # lazily: [[A_ub, I], [A_eq, 0]] (:145-156)
+            A_ub, _, A_eq, _, c = self._parts
+            m_ub, m_eq, n = A_ub.shape[0], A_eq.shape[0], c.shape[0]
+            A = np.zeros((m_ub + m_eq, n + m_ub))
+            A[:m_ub, :n] = A_ub
+            A[m_ub:, :n] = A_eq
+            A[np.arange(m_ub), n + np.arange(m_ub)] = 1.0
+            self._A = A
         return self._A
 
     def b(self) -> np.ndarray:                   # :47-49
@@ -165,16 +176,9 @@ class ProblemBuilder:
         if (A_ub.shape[1] != A_eq.shape[1] or A_eq.shape[1] != n or m_ub != b_ub.shape[0]
                 or m_eq != b_eq.shape[0]):                                   # :137-143
             raise IncompatibleInputDimensions()
-        m, ns = m_ub + m_eq, n + m_ub
-        A = np.empty((m, ns))
-        b = np.empty(m)
-        cs = np.empty(ns)
-        nsl = C.c_uint64(0)
-        rc = _capi.lib().lpipm_problem_build(n, m_ub, _p(A_ub) if m_ub else None, _p(b_ub) if m_ub else None,
-                                             m_eq, _p(A_eq) if m_eq else None, _p(b_eq) if m_eq else None,
-                                             _p(c), _p(A), _p(b), _p(cs), C.byref(nsl))
-        _raise_for(rc)
-        return Problem(A, b, cs, 0.0, nsl.value)
+        b = np.concatenate([b_ub, b_eq])                                     # :157-158
+        cs = np.concatenate([c, np.zeros(m_ub)])                             # :159-160
+        return Problem(None, b, cs, 0.0, m_ub, parts=(A_ub, b_ub, A_eq, b_eq, c))   # :161; A on demand
 
 
 # ------------------------------------------------------------------------------ solvers/mod.rs
@@ -234,6 +238,16 @@ class Context:
             pass
 
     def upload(self, problem: Problem, use_slack_structure: bool = True):
+        if use_slack_structure and getattr(problem, "_parts", None) is not None:
+            # device-side assembly: the ub / eq blocks as given, no host slack matrix (lpipm_upload_ub_eq)
+            A_ub, b_ub, A_eq, b_eq, c = problem._parts
+            m_ub, m_eq, n = A_ub.shape[0], A_eq.shape[0], c.shape[0]
+            rc = _capi.lib().lpipm_upload_ub_eq(self._h, n, m_ub, _p(A_ub) if m_ub else None, n, _p(b_ub) if m_ub else None,
+                                                m_eq, _p(A_eq) if m_eq else None, n, _p(b_eq) if m_eq else None,
+                                                _p(c), float(problem.c0()))
+            _raise_for(rc)
+            self.m, self.n = m_ub + m_eq, n + m_ub
+            return self
         A, b, c = _f64(problem.A()), _f64(problem.b()), _f64(problem.c())
         return self.upload_arrays(A, b, c, problem.c0(), problem.n_slack() if use_slack_structure else 0)
 

@@ -42,6 +42,7 @@ SYMBOLS = {
     "lpipm_destroy": (None, [_vp]),
     "lpipm_upload": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
     "lpipm_upload_slack": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double, _u64]),
+    "lpipm_upload_ub_eq": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _u64, _dp, _u64, _dp, _dp, C.c_double]),
     "lpipm_solve": (C.c_int, [_vp, C.POINTER(Opts), _dp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_device": (C.c_int, [_vp, C.POINTER(Opts), _vp, _dp, C.POINTER(_u64), C.POINTER(IterRow)]),
     "lpipm_solve_batch": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,

@@ -323,17 +323,24 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
 }
 
 // count LPs of one geometry (count == 1: the ordinary upload).  A/b/cc/c0: one entry per LP.
+// `parts` (count == 1 only): the rows come as two blocks of nx = n - n_slack columns -- m_ub rows of A_ub, then
+// m - m_ub rows of A_eq -- with b split the same way and c holding only the nx structural costs; the slack
+// structure is then true by construction (lpipm_upload_ub_eq).
+struct UploadParts { uint64_t m_ub; const double* A_ub; uint64_t lda_ub; const double* b_ub;
+                     const double* A_eq; uint64_t lda_eq; const double* b_eq; };
 static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const double* const* A, uint64_t lda,
-                       const double* const* b, const double* const* cc, const double* c0, uint64_t n_slack) {
-    if (!c || count < 1 || !A || !b || !cc || lda < n) return LPIPM_ERR_BAD_ARGUMENT;
+                       const double* const* b, const double* const* cc, const double* c0, uint64_t n_slack,
+                       const UploadParts* parts = nullptr) {
+    if (!c || count < 1 || !cc) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!parts && (!A || !b || lda < n)) return LPIPM_ERR_BAD_ARGUMENT;
     for (int i = 0; i < count; ++i)
-        if (!A[i] || !b[i] || !cc[i]) return LPIPM_ERR_BAD_ARGUMENT;
+        if (!cc[i] || (!parts && (!A[i] || !b[i]))) return LPIPM_ERR_BAD_ARGUMENT;
     if (m == 0) return LPIPM_UNCONSTRAINED;  // linear_program.rs:134-136
     if (n == 0 || m > (1u << 20) || n > (1u << 24) || n_slack > n || n_slack > m) return LPIPM_ERR_BAD_ARGUMENT;
     // The hint is only used if the last n_slack columns really are [I; 0] (ProblemBuilder::build
     // guarantees it, linear_program.rs:147-156); anything else is treated as a dense matrix.
-    if (n_slack == n || count > 1) n_slack = 0;
-    for (uint64_t i = 0; i < m && n_slack; ++i) {
+    if (!parts && (n_slack == n || count > 1)) n_slack = 0;
+    for (uint64_t i = 0; i < m && n_slack && !parts; ++i) {
         const double* row = A[0] + i * lda + (n - n_slack);
         for (uint64_t j = 0; j < n_slack; ++j)
             if (row[j] != ((i == j) ? 1.0 : 0.0)) { n_slack = 0; break; }
@@ -408,7 +415,23 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     c->va.done_chk = c->bt.done;
     std::vector<double> c0v((size_t)count, 0.0);          // must outlive the asynchronous copies below
     for (int i = 0; i < count; ++i) c0v[i] = c0 ? c0[i] : 0.0;
-    for (int i = 0; i < count; ++i) {
+    if (parts) {   // rows of A_ub, then rows of A_eq; b likewise; c = [c; 0] (the arena is zero)
+        const uint64_t m_ub = parts->m_ub, m_eq = m - m_ub;
+        if (m_ub) {
+            LP_HIP(hipMemcpy2DAsync(c->A, (size_t)npa * sizeof(double), parts->A_ub, (size_t)parts->lda_ub * sizeof(double),
+                                    (size_t)nx * sizeof(double), (size_t)m_ub, hipMemcpyHostToDevice, st));
+            LP_HIP(hipMemcpyAsync((void*)c->va.b, parts->b_ub, m_ub * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        if (m_eq) {
+            LP_HIP(hipMemcpy2DAsync(c->A + (size_t)m_ub * npa, (size_t)npa * sizeof(double), parts->A_eq,
+                                    (size_t)parts->lda_eq * sizeof(double), (size_t)nx * sizeof(double), (size_t)m_eq,
+                                    hipMemcpyHostToDevice, st));
+            LP_HIP(hipMemcpyAsync((void*)(c->va.b + m_ub), parts->b_eq, m_eq * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        LP_HIP(hipMemcpyAsync((void*)c->va.c, cc[0], nx * sizeof(double), hipMemcpyHostToDevice, st));
+        LP_HIP(hipMemcpyAsync((void*)(c->va.S + S_C0), &c0v[0], sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    for (int i = 0; i < count && !parts; ++i) {
         const size_t off = (size_t)i * c->bstride;
         LP_HIP(hipMemcpy2DAsync((char*)c->A + off, (size_t)npa * sizeof(double), A[i], (size_t)lda * sizeof(double),
                                 (size_t)nx * sizeof(double), (size_t)m, hipMemcpyHostToDevice, st));
@@ -429,6 +452,16 @@ extern "C" int lpipm_upload(lpipm_ctx* c, uint64_t m, uint64_t n, const double* 
 extern "C" int lpipm_upload_slack(lpipm_ctx* c, uint64_t m, uint64_t n, const double* A, uint64_t lda,
                                   const double* b, const double* cc, double c0, uint64_t n_slack) {
     return upload_impl(c, 1, m, n, &A, lda, &b, &cc, &c0, n_slack);
+}
+
+extern "C" int lpipm_upload_ub_eq(lpipm_ctx* c, uint64_t n, uint64_t m_ub, const double* A_ub, uint64_t lda_ub,
+                                  const double* b_ub, uint64_t m_eq, const double* A_eq, uint64_t lda_eq,
+                                  const double* b_eq, const double* cc, double c0) {
+    if (m_ub + m_eq == 0) return LPIPM_UNCONSTRAINED;                       // linear_program.rs:134-136
+    if (!cc || n == 0 || (m_ub && (!A_ub || !b_ub || lda_ub < n)) || (m_eq && (!A_eq || !b_eq || lda_eq < n)))
+        return LPIPM_ERR_BAD_ARGUMENT;
+    const UploadParts parts{m_ub, A_ub, lda_ub, b_ub, A_eq, lda_eq, b_eq};
+    return upload_impl(c, 1, m_ub + m_eq, n + m_ub, nullptr, 0, nullptr, &cc, &c0, m_ub, &parts);
 }
 
 // ------------------------------------------------------------------------------------------------

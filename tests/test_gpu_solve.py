@@ -388,3 +388,39 @@ def test_rank_deficient_constraints_are_a_numerical_problem(ctx, case):
     assert rc == _capi.NUMERICAL_PROBLEM and it <= ref["iterations"] + 1
     with pytest.raises(lp_amd.NumericalProblem):
         lp_amd.InteriorPoint.default().solve(lp_amd.Problem.target(c).eq(A2, b2).build())
+
+
+def test_device_side_slack_assembly_is_bit_identical(ctx):
+    """lpipm_upload_ub_eq (the ub / eq blocks as the builder got them, linear_program.rs:145-160 done on the device)
+    against lpipm_problem_build + lpipm_upload_slack of the explicit slack-form matrix: same device image, so the
+    solves are bit-identical; ub-only and eq-only problems included."""
+    import lp_amd
+    rng = np.random.default_rng(11)
+    n, m_ub, m_eq = 90, 70, 25
+    x0 = rng.uniform(0.5, 2.0, n)
+    A_ub = rng.standard_normal((m_ub, n)); b_ub = A_ub @ x0 + rng.uniform(0.1, 1.0, m_ub)
+    A_eq = rng.standard_normal((m_eq, n)); b_eq = A_eq @ x0
+    c = rng.uniform(0.1, 1.0, n)
+    o = lp_amd.InteriorPoint.default().opts()
+    for (ub, eq) in (((A_ub, b_ub), (A_eq, b_eq)), ((A_ub, b_ub), None), (None, (A_eq[:, :n], b_eq))):
+        bld = lp_amd.Problem.target(c)
+        if ub is not None:
+            bld = bld.ub(*ub)
+        if eq is not None:
+            bld = bld.eq(*eq)
+        prob = bld.build()
+        assert prob._A is None                                   # no host slack matrix so far
+        ctx.upload(prob)                                         # device-side assembly
+        r_dev = ctx.solve_raw(o, want_log=True)
+        A = prob.A()                                             # now built on the host: [[A_ub, I], [A_eq, 0]]
+        assert A.shape == (prob.b().shape[0], n + prob.n_slack())
+        ctx.upload_arrays(A, prob.b(), prob.c(), prob.c0(), prob.n_slack())
+        r_host = ctx.solve_raw(o, want_log=True)
+        assert r_dev[0] == r_host[0] and r_dev[3] == r_host[3] and r_dev[4] == r_host[4]
+        if r_dev[0] == 0:
+            assert np.array_equal(r_dev[1], r_host[1]) and r_dev[2] == r_host[2]
+            x = prob.denormalize_x_into(r_dev[1])
+            if ub is not None:
+                assert (ub[0] @ x <= ub[1] + 1e-7).all()
+            if eq is not None:
+                assert np.abs(eq[0] @ x - eq[1]).max() <= 1e-7
