@@ -140,7 +140,9 @@ int lpipm_solve_device(lpipm_ctx* ctx, const lpipm_opts* opts, void* x_dev_out, 
 /* A shard of independent LPs on ONE device (BASELINE config 4): problem i is m[i] x n[i] with
  * A[i] (lda = n[i]), b[i], c[i], c0[i]; results go to x_slack_out[i] (n[i] doubles), fun_out[i],
  * iterations_out[i], status_out[i].  Returns the first non-Ok *runtime* status (>= 100) or Ok;
- * per-problem solver outcomes (Infeasible, ...) are reported in status_out only. */
+ * per-problem solver outcomes (Infeasible, ...) are reported in status_out only.
+ * Members of equal shape are solved as lockstep batches (below), the others one at a time on worker contexts.
+ * The call replaces the context's uploaded problem: upload again before a later lpipm_solve on this context. */
 int lpipm_solve_batch(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const uint64_t* n,
                       const double* const* A, const double* const* b, const double* const* c,
                       const double* c0, const lpipm_opts* opts, double* const* x_slack_out,
