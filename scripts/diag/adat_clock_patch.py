@@ -6,7 +6,7 @@ random data, median over workgroups).
 Usage on the box:  python scripts/diag/adat_clock_patch.py && make -C lp_amd/csrc && python scripts/diag/adat_clock_run.py"""
 p = 'lp_amd/csrc/kernels_gemm.hip'
 s = open(p).read()
-s = s.replace('#include "lpipm_internal.hpp"\n', '#include "lpipm_internal.hpp"\n#include <cstdio>\n#include <vector>\n#include <algorithm>\n', 1)
+s = s.replace('#include "lpipm_internal.hpp"\n', '#include "lpipm_internal.hpp"\n#include <cstdio>\n#include <cstdlib>\n#include <vector>\n#include <algorithm>\n', 1)
 s = s.replace("template <bool SCALE>\n__device__ __forceinline__ void tile_mainloop_w8(",
               "static __device__ unsigned long long g_clk[4 * 1024];\ntemplate <bool SCALE>\n__device__ __forceinline__ void tile_mainloop_w8(", 1)
 a = s.index("__device__ __forceinline__ void tile_mainloop_w8(")
@@ -28,6 +28,8 @@ s = s.replace("hipError_t launch_gemm_grouped(", """void dbg_print_clock() {
             cpk.push_back((double)h[4 * b] / (double)h[4 * b + 2]);
         }
     if (ghz.empty()) { fprintf(stderr, "no stamps\\n"); return; }
+    if (getenv("LPIPM_DIAG_PER_WG"))   // b = blockIdx.x, logical index g = xcd*64 + b/8 (512 workgroups)
+        for (int b = 0; b < 512; ++b) fprintf(stderr, "wg %d g %d cpk %.0f\\n", b, (b & 7) * 64 + (b >> 3), (double)h[4 * b] / (double)h[4 * b + 2]);
     std::sort(ghz.begin(), ghz.end()); std::sort(cpk.begin(), cpk.end());
     const size_t n = ghz.size();
     fprintf(stderr, "A.D.A^T data-parallel tiles, %zu workgroups: in-kernel clock median %.3f GHz (min %.3f, max %.3f); "
