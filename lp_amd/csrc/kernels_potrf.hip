@@ -18,7 +18,7 @@ namespace lpipm {
 constexpr int SB  = 16;        // sub-block edge inside the diagonal block
 constexpr int NSB = NB / SB;   // 8
 constexpr int LS  = NB + 2;    // LDS row stride in doubles (260 dwords: rows 4 banks apart)
-constexpr int DT  = 512;       // threads of the diagonal-block kernel (8 waves, 2 per SIMD)
+constexpr int DT  = 1024;      // threads of the diagonal-block kernel: 16 waves (3 eliminate, 13 update), 4 per SIMD
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -275,7 +275,7 @@ __device__ __forceinline__ void update_tiles(double (*Ls)[LS], const double (*xi
 // 128 other rows (panel rows below, identity rows above / inside the block).  The rank-16 update of
 // everything to the right runs as 16x16 MFMA tiles and is software-pipelined against the
 // elimination: first the 8 tiles of the NEXT block column (one per wave), barrier, then waves 0..2
-// eliminate that column while waves 3..7 apply the rest of the update.
+// eliminate that column while waves 3..15 apply the rest of the update.
 __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mblk, long long ld,
                                                         double* __restrict__ Linv, double* __restrict__ LinvT,
                                                         long long ldinv, int32_t* info, int global_row0,
