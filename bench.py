@@ -138,9 +138,12 @@ def main():
         # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (counters
         # cannot be read from inside this process); the committed summary is profiles/r01_adat_pmc.json.
         traffic = None
+        mfma_busy = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_adat_pmc.json")
         if (m, n) == (4096, 8192) and os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get("traffic_bytes_per_launch")
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("traffic_bytes_per_launch")
+            mfma_busy = pmc.get("mfma_busy_fraction")
         out = {
             "metric": "IPM iterations/sec, dense 4096x8192 fp64 LP",
             "value": iters_total / dt_max,
@@ -165,6 +168,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, "
                                                              "profiles/r01_adat_pmc.json)",
                          "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
+                         "mfma_busy_pmc": mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES share of the kernel's SIMD-cycles (same JSON)
                          "avg_launch_ms": avg_ms, "launches": adat_launches,
                          "flops_per_launch": flops_per_launch},
             "phase_ms_per_iteration": {k: v / phase_iters for k, v in phase.items()},
