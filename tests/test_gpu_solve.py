@@ -424,3 +424,19 @@ def test_device_side_slack_assembly_is_bit_identical(ctx):
                 assert (ub[0] @ x <= ub[1] + 1e-7).all()
             if eq is not None:
                 assert np.abs(eq[0] @ x - eq[1]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 17), (2, 3), (3, 1000), (8, 100000), (127, 129), (128, 129), (129, 130),
+                                 (257, 300), (511, 512), (1025, 1100)])
+def test_awkward_shapes_match_oracle(ctx, m, n):
+    """Edge geometry: single row / column, sizes one off the 128-row and 16-column padding, nearly square, very wide."""
+    import lp_amd
+    from lp_amd import synth
+    from oracle import capi as oracle
+    A, b, c, _ = synth.planted_lp(m * 31 + n, m, n)
+    ref = oracle.solve(A, b, c)
+    ctx.upload_arrays(A, b, c)
+    rc, x, fun, it, _ = ctx.solve_raw(lp_amd.InteriorPoint.default().opts())
+    assert rc == ref["status"] == 0 and it == ref["iterations"]
+    assert np.abs(x - ref["x_slack"]).max() <= 1e-6
+    assert abs(fun - ref["fun"]) <= 1e-6 * max(1.0, abs(ref["fun"]))
