@@ -1,0 +1,71 @@
+// Host-logic exerciser for an AddressSanitizer / UBSan build of liblpipm.so (scripts/diag/host_asan.sh): uploads of
+// changing geometry, single solves, lockstep batches, a mixed-shape lpipm_solve_batch (grouping, chunk pipeline, worker
+// threads), the ub/eq upload, error paths.  Exit code 0 = all answers as expected and no sanitizer report.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "lpipm.h"
+
+struct LP { uint64_t m, n; std::vector<double> A, b, c, xs; };
+static LP make(uint64_t seed, uint64_t m, uint64_t n) {
+    LP p{m, n, std::vector<double>(m * n), std::vector<double>(m), std::vector<double>(n), std::vector<double>(n)};
+    if (lpipm_synth_planted_lp(seed, m, n, p.A.data(), p.b.data(), p.c.data(), p.xs.data()) != 0) { printf("synth failed\n"); exit(2); }
+    return p;
+}
+static double maxerr(const std::vector<double>& x, const std::vector<double>& y) {
+    double e = 0; for (size_t i = 0; i < x.size(); ++i) e = std::fmax(e, std::fabs(x[i] - y[i])); return e;
+}
+#define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+int main() {
+    lpipm_ctx* ctx = nullptr;
+    CHECK(lpipm_create(0, &ctx) == 0);
+    lpipm_opts o; lpipm_default_opts(&o);
+    // single solves, geometry changing up and down
+    for (auto mn : {std::pair<uint64_t, uint64_t>{64, 160}, {300, 700}, {1, 1}, {129, 130}, {64, 160}}) {
+        LP p = make(mn.first + mn.second, mn.first, mn.second);
+        CHECK(lpipm_upload(ctx, p.m, p.n, p.A.data(), p.n, p.b.data(), p.c.data(), 0.0) == 0);
+        std::vector<double> x(p.n); double fun; uint64_t it;
+        std::vector<lpipm_iter_row> log(o.max_iter);
+        CHECK(lpipm_solve(ctx, &o, x.data(), &fun, &it, log.data()) == 0);
+        CHECK(maxerr(x, p.xs) < 1e-5);
+    }
+    // lockstep batch + mixed-shape batch (groups of equal shape, an odd one, chunks of 3 -> pipeline over two contexts)
+    std::vector<LP> lps;
+    for (int s = 0; s < 7; ++s) lps.push_back(make(s, 96, 200));
+    lps.push_back(make(77, 40, 100));
+    for (int s = 0; s < 3; ++s) lps.push_back(make(20 + s, 130, 300));
+    const size_t K = lps.size();
+    std::vector<uint64_t> m(K), n(K), its(K);
+    std::vector<const double*> A(K), b(K), c(K);
+    std::vector<std::vector<double>> xs(K);
+    std::vector<double*> xp(K);
+    std::vector<double> fun(K);
+    std::vector<int32_t> st(K);
+    for (size_t i = 0; i < K; ++i) { m[i] = lps[i].m; n[i] = lps[i].n; A[i] = lps[i].A.data(); b[i] = lps[i].b.data(); c[i] = lps[i].c.data(); xs[i].resize(n[i]); xp[i] = xs[i].data(); }
+    for (int mode : {-1, 3, 0}) {
+        CHECK(lpipm_set_batch_lockstep(ctx, mode) == 0);
+        CHECK(lpipm_solve_batch(ctx, K, m.data(), n.data(), A.data(), b.data(), c.data(), nullptr, &o, xp.data(), fun.data(), its.data(), st.data()) == 0);
+        for (size_t i = 0; i < K; ++i) { CHECK(st[i] == 0); CHECK(maxerr(xs[i], lps[i].xs) < 1e-5); }
+    }
+    CHECK(lpipm_upload_lockstep(ctx, 7, 96, 200, A.data(), b.data(), c.data(), nullptr) == 0);
+    CHECK(lpipm_solve_lockstep(ctx, &o, xp.data(), fun.data(), its.data(), st.data()) == 0);
+    for (int i = 0; i < 7; ++i) CHECK(st[i] == 0);
+    // ub / eq upload (README LP: known answer [1, 0])
+    const double c2[2] = {-1, 4}, Aub[4] = {-3, 1, 1, 2}, bub[2] = {6, 4}, Aeq[2] = {1, 1}, beq[1] = {1};
+    CHECK(lpipm_upload_ub_eq(ctx, 2, 2, Aub, 2, bub, 1, Aeq, 2, beq, c2, 0.0) == 0);
+    double x4[4], f4; uint64_t it4;
+    CHECK(lpipm_solve(ctx, &o, x4, &f4, &it4, nullptr) == 0);
+    CHECK(std::fabs(x4[0] - 1.0) < 1e-6 && std::fabs(x4[1]) < 1e-6);
+    // error paths
+    CHECK(lpipm_upload_ub_eq(ctx, 2, 0, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, c2, 0.0) == LPIPM_UNCONSTRAINED);
+    lpipm_opts bad = o; bad.alpha0 = 2.0;
+    CHECK(lpipm_solve(ctx, &bad, x4, &f4, &it4, nullptr) == LPIPM_INVALID_PARAMETER);
+    const double Ainf[4] = {1, 1, 1, 1}, binf[1] = {-1}, cinf[4] = {1, 1, 1, 1};
+    CHECK(lpipm_upload(ctx, 1, 4, Ainf, 4, binf, cinf, 0.0) == 0);
+    CHECK(lpipm_solve(ctx, &o, x4, &f4, &it4, nullptr) == LPIPM_INFEASIBLE);
+    lpipm_destroy(ctx);
+    printf("host exerciser ok\n");
+    return 0;
+}
