@@ -11,6 +11,9 @@ Weak scaling: every rank owns ONE independent LP of the same shape (seed = rank)
 one per GPU with no data-path collective -- and the timed region ends with the single RCCL
 all-gather of the solutions.  value = IPM iterations of all ranks / max-over-ranks wall time.
 
+`--workload c4` (optional, not the default): BASELINE config 4 instead -- 32 independent 1024x2048 LPs per GPU as one
+lockstep batch with resident inputs, value in LP/s; same timing protocol, no roofline / cpu_baseline objects.
+
 Extra objects on the JSON line:
   roofline     : the dominant kernel (A.D.A^T, MFMA-bound): algorithmic flops m(m+1)n per launch /
                  its average launch duration from HIP events recorded on the solver's own stream
@@ -43,6 +46,9 @@ def main():
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("c3", "c4"), default="c3",
+                    help="c3 (default, the BASELINE metric): one 4096x8192 LP per GPU; c4: a shard of 32 independent "
+                         "1024x2048 LPs per GPU as one lockstep batch (BASELINE config 4: 256 LPs over 8 GPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,6 +76,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
 
+    if args.workload == "c4":
+        return bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth)
     m, n = args.m, args.n
     A, b, c, xstar = synth.planted_lp(rank, m, n)        # one independent LP per rank (seed = rank)
     ctx = lp_amd.Context(local_rank)
@@ -187,6 +195,58 @@ def main():
                 "phase_s": r["timing"],
             }
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth):
+    """BASELINE config 4: 32 independent 1024x2048 LPs per GPU (256 over 8), solved as ONE lockstep batch with the inputs
+    resident in HBM, then the single gather of the solutions.  value = LPs of all ranks / max-over-ranks wall time."""
+    import time
+    per_rank, m, n = 32, 1024, 2048
+    probs = [synth.planted_lp(rank * per_rank + s, m, n) for s in range(per_rank)]
+    ctx = lp_amd.Context(local_rank)
+    ctx.upload_lockstep([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs])   # untimed H2D
+    opts = lp_amd.InteriorPoint.default().opts()
+    gathered = torch.zeros(world * per_rank * n, dtype=torch.float64, device=dev) if dist is not None else None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        res = ctx.solve_lockstep(opts)
+        if any(r[0] != 0 for r in res):
+            raise RuntimeError("a member of the shard did not solve")
+        if dist is not None:                              # the single RCCL gather of the batch's solutions
+            xs = torch.from_numpy(np.stack([r[1] for r in res]).reshape(-1)).to(dev)
+            dist.all_gather_into_tensor(gathered, xs)
+        return res
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    its = sum(r[3] for r in res)
+    err = max(float(np.abs(r[1] - p[3]).max()) for r, p in zip(res, probs))
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "independent LPs solved per second, batch of 1024x2048 fp64 LPs sharded 32 per GPU", "value": world * per_rank * args.steps / dt,
+            "unit": "LP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C4: {world * per_rank} independent planted LPs m={m} n={n} fp64, {per_rank} per GPU as one lockstep batch, "
+                                   "inputs resident in HBM, one all-gather of the solutions",
+                       "iterations_per_lp": its / per_rank, "max_abs_err_vs_planted_optimum": err}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
