@@ -35,6 +35,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_RESULT_FD = 1
+
+
+def emit(obj):
+    os.write(_RESULT_FD, (json.dumps(obj) + "\n").encode())
+
+
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (probe: lpipm_k_mfma_f64_probe ~76 TF/s)
 
 
@@ -50,6 +57,13 @@ def main():
                     help="c3 (default, the BASELINE metric): one 4096x8192 LP per GPU; c4: a shard of 32 independent "
                          "1024x2048 LPs per GPU as one lockstep batch (BASELINE config 4: 256 LPs over 8 GPUs)")
     args = ap.parse_args()
+
+    # STDOUT carries exactly one line, the JSON result.  Libraries that print to file descriptor 1 on their own (RCCL's
+    # version banner under NCCL_DEBUG=VERSION, warnings) are sent to stderr for the lifetime of the process.
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -194,7 +208,7 @@ def main():
                           f"every iteration performs the same operations",
                 "phase_s": r["timing"],
             }
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -240,13 +254,13 @@ def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "independent LPs solved per second, batch of 1024x2048 fp64 LPs sharded 32 per GPU", "value": world * per_rank * args.steps / dt,
             "unit": "LP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4: {world * per_rank} independent planted LPs m={m} n={n} fp64, {per_rank} per GPU as one lockstep batch, "
                                    "inputs resident in HBM, one all-gather of the solutions",
-                       "iterations_per_lp": its / per_rank, "max_abs_err_vs_planted_optimum": err}}), flush=True)
+                       "iterations_per_lp": its / per_rank, "max_abs_err_vs_planted_optimum": err}})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
