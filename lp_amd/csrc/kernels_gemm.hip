@@ -32,6 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int LDS_STRIDE = BK + 2;  // doubles per LDS row (144 B, keeps 16-B alignment)
+constexpr int SK_CHUNK = 16;        // k-tiles per dynamically claimed stream-K chunk
 
 struct GemmK {
     const double* P; long long ldp;
@@ -45,6 +46,7 @@ struct GemmK {
     int diag_pad_from;
     double* ws;
     int nwg;
+    unsigned int* sk_claim;   // see GemmArgs
     BatchK bk;
 };
 // LP blockIdx.z of a lockstep batch: per-LP pointers shifted (the tile list is shared)
@@ -351,6 +353,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                 wc, fr, fq);
         store_tile(acc, ti, tj);
     }
+    if (p.sk_claim) {
+        // Dynamic stream-K: the remainder tiles' k-ranges in chunks of SK_CHUNK k-tiles, claimed through one device word.
+        // The static split below hands every workgroup exactly one such chunk (at C3: 16 tiles x 512 k-tiles over 512
+        // workgroups), but the data-parallel tiles do not all finish together (stamps: 1876 .. 2025 us), so the static
+        // version ends 67 us after the slowest of them; claimed chunks go to whoever is free.  Slab c holds chunk c and the
+        // fix-up adds a tile's slabs in chunk order: same partial sums, same order, same bits as the static split.
+        __shared__ int s_claim;
+        const int cpt = KT / SK_CHUNK, nchunks = (p.ntiles - ntiles_dp) * cpt;
+        for (;;) {
+            if (tid == 0) s_claim = (int)atomicAdd(p.sk_claim, 1u);
+            __syncthreads();
+            const int ch = s_claim;
+            __syncthreads();
+            if (ch >= nchunks) break;
+            const int rt = ch / cpt, kb = (ch - rt * cpt) * SK_CHUNK;
+            int ti, tj;
+            tile_coords(p, ntiles_dp + rt, ti, tj);
+            d4 acc[4][2];
+            zero(acc);
+            tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
+                                    p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, kb + SK_CHUNK, acc, srow,
+                                    scol, wr, wc, fr, fq);
+            double* sb0 = p.ws + (long long)ch * (TILE * TILE) + (wr * 64 + fq) * TILE + wc * 32 + fr;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
+        }
+        return;
+    }
     const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
     long long it = wg_begin(g, total, p.nwg);
     const long long end = wg_begin(g + 1, total, p.nwg);
@@ -519,7 +553,9 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
     const int rt = bx / FIX_SPLIT, chunk = bx % FIX_SPLIT;
     const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
     const long long it0 = (long long)rt * KT, it1 = it0 + KT;
-    const int g_lo = wg_owner(it0, total, p.nwg), g_hi = wg_owner(it1 - 1, total, p.nwg);
+    const bool dyn = p.sk_claim != nullptr;          // slabs [rt*cpt, (rt+1)*cpt), one per claimed chunk
+    const int cpt = KT / SK_CHUNK;
+    const int g_lo = dyn ? rt * cpt : wg_owner(it0, total, p.nwg), g_hi = dyn ? rt * cpt + cpt - 1 : wg_owner(it1 - 1, total, p.nwg);
     if (g_lo == g_hi) return;  // one workgroup computed the whole tile and wrote it directly
     int ti, tj;
     tile_coords(p, ntiles_dp + rt, ti, tj);
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
         d2 sum = (d2){0.0, 0.0};
         for (int g = g_lo; g <= g_hi; ++g) {
             const int slot = wg_begin(g, total, p.nwg) >= it0 ? 0 : 1;
-            sum += *(const d2*)(p.ws + ((long long)(2 * g + slot)) * (TILE * TILE) + e);
+            sum += *(const d2*)(p.ws + (dyn ? (long long)g : (long long)(2 * g + slot)) * (TILE * TILE) + e);
         }
         const int r = e / TILE, c = e - r * TILE;
         const int row = ti * TILE + r, col = tj * TILE + c;
@@ -557,6 +593,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.C = a.C; k.ldc = a.ldc; k.KT = a.K / BK; k.alpha = a.alpha; k.beta = a.beta;
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg; k.bk = batch_k(a.batch);
+    k.sk_claim = nullptr;
     const int B = a.batch.count;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
     if (a.nwg == a.ntiles && !a.s && a.diag_pad_from < 0) {   // one whole tile per workgroup
@@ -572,6 +609,15 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.bk.xcd_major = xm ? 1 : 0;
     const dim3 grid = xm ? dim3(8, a.nwg, B / 8) : dim3(a.nwg, 1, B);
     static const bool w4 = getenv("LPIPM_ADAT_W4") != nullptr;   // measurement knob: the 4-wave form (scripts/adat_ab.py)
+    static const bool sk_static = getenv("LPIPM_SK_STATIC") != nullptr;   // measurement knob: static stream-K split
+    // dynamic claiming of the remainder chunks: single LP, 8-wave kernel, a data-parallel phase exists, chunks divide K
+    const int nrem_ = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
+    if (a.sk_claim && !w4 && !sk_static && B == 1 && a.ntiles >= a.nwg && nrem_ > 0 && k.KT % SK_CHUNK == 0 && k.KT > SK_CHUNK &&
+        nrem_ * (k.KT / SK_CHUNK) <= 2 * a.nwg) {
+        hipError_t em = hipMemsetAsync(a.sk_claim, 0, sizeof(unsigned int), st);
+        if (em != hipSuccess) return em;
+        k.sk_claim = a.sk_claim;
+    }
     if (a.s && !w4) hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<true>, grid, dim3(512), 0, st, k);
     else if (a.s)   hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
     else if (!w4)   hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<false>, grid, dim3(512), 0, st, k);
@@ -583,7 +629,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     const long long total = (long long)nrem * k.KT;
     bool split = false;
     for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
-    if (split) {
+    if (split || k.sk_claim) {
         hipLaunchKernelGGL(gemm_nt_fixup_kernel, xm ? dim3(8, nrem * FIX_SPLIT, B / 8) : dim3(nrem * FIX_SPLIT, 1, B), dim3(256), 0,
                            st, k);
         e = hipGetLastError();

@@ -94,6 +94,9 @@ struct GemmArgs {
     int           diag_pad_from;// rows/cols >= this on the diagonal are written as 1.0 (-1: off)
     double*       ws;           // stream-K partial slabs: 2 per workgroup, TILE*TILE doubles each
     int           nwg;          // workgroups launched (== grid); ntiles*KT split evenly
+    unsigned int* sk_claim;     // nullable (single LP, 8-wave kernel): a zeroed device word -> the k-chunks of the stream-K
+                                //   remainder tiles are claimed dynamically (workgroups that finish their data-parallel
+                                //   tile early take more of them); slabs are indexed by chunk, so the sums do not change
     int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
     Batch         batch;        // lockstep batch (every pointer above except tile_list is per LP)
 };

@@ -57,6 +57,7 @@ struct lpipm_ctx {
     double *tau = nullptr, *ktau = nullptr;   // Householder scalars of the QR arms
     double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
     int2* tile_list = nullptr;
+    unsigned int* sk_claim = nullptr;   // claim word of the dynamic stream-K chunks of A.D.A^T
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
     StatusRec* status_host = nullptr;  // pinned, status_cap records
@@ -317,6 +318,7 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
+    c->sk_claim = ar.take<unsigned int>(1);
     // stream-K slabs of A.D.A^T: only when a tile's k-range can be split over workgroups
     c->ws = ar.take<double>(c->adat_nwg == c->ntiles ? 1 : (size_t)2 * c->adat_nwg * TILE * TILE);
     return LPIPM_OK;
@@ -485,7 +487,7 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     g.P = c->A; g.ldp = c->npa; g.Q = c->A; g.ldq = c->npa; g.s = c->va.dinv;
     g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
-    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt;
+    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt; g.sk_claim = c->sk_claim;
     hipError_t e = launch_gemm_nt(g, c->st);
     if (e != hipSuccess) return e;
     return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
