@@ -17,10 +17,19 @@
 //   * k-tiles of 16 are register-staged (global_load_dwordx4: 8 lanes x 16 B = one full 128-B line
 //     per row), written to a double-buffered padded LDS image (row stride 18 doubles: the 16
 //     rows x 2 k-groups of a 32-lane LDS phase land on distinct banks), one barrier per k-tile.
-//   * stream-K: ntiles*KT k-tile iterations are split evenly over the launched workgroups
-//     (528 lower tiles at m=4096 do not divide over 512 resident workgroups); a workgroup's
-//     partial first/last tile goes to a slab and a second pass adds the slabs of a tile in
-//     workgroup order -- deterministic, no atomics.
+//   * data-parallel + stream-K hybrid: whole tiles while they divide over the resident workgroups,
+//     the remaining tiles' k-range in CHUNKS claimed through one device word (528 lower tiles at
+//     m=4096 do not divide over 512 resident workgroups); a chunk's partial tile goes to a slab and
+//     a second pass adds the slabs of a tile in chunk order -- deterministic, no data atomics.
+//   * CANONICAL SUMMATION ORDER (A.D.A^T): the contraction is cut into chunks of kc k-tiles (256
+//     columns up to n = 4096, the KC panel depth of the reference's dgemm -- matrixmultiply, whose
+//     `C += A_panel . B_panel` per packed panel is restated in oracle/oracle_linalg.c); every chunk is
+//     summed from zero in k order and the chunk sums are added in chunk order.  A data-parallel tile
+//     flushes its accumulators into C at every chunk boundary, a stream-K chunk goes to its slab and
+//     the fix-up adds the slabs in the same order: M has the same bits whatever the decomposition
+//     (single LP, lockstep batch, any workgroup count), and the rounding error of a length-n sum is
+//     that of a two-level sum, like the reference's, instead of a length-n running sum (measured on
+//     the 256 C4 members: without it the lockstep path ended one-sidedly further from the vertex).
 //   * workgroups are renumbered so that the 64 that share an XCD (and its L2) work on one
 //     8x8 super-block of tiles: 16 row panels of A feed 64 tiles.
 #include "lpipm_internal.hpp"
@@ -32,7 +41,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int LDS_STRIDE = BK + 2;  // doubles per LDS row (144 B, keeps 16-B alignment)
-constexpr int SK_CHUNK = 16;        // k-tiles per dynamically claimed stream-K chunk
+constexpr int SK_CHUNK = 16;        // k-tiles per dynamically claimed stream-K chunk when no canonical chunk is set
 
 struct GemmK {
     const double* P; long long ldp;
@@ -47,13 +56,14 @@ struct GemmK {
     double* ws;
     int nwg;
     unsigned int* sk_claim;   // see GemmArgs
+    int kc;                   // canonical summation chunk in k-tiles (0: plain running sum over the whole k-range)
     BatchK bk;
 };
 // LP blockIdx.z of a lockstep batch: per-LP pointers shifted (the tile list is shared)
 __device__ __forceinline__ GemmK batch_shift(const GemmK& p0) {
     GemmK p = p0;
     p.P = batch_ptr(p0.P, p0.bk); p.Q = batch_ptr(p0.Q, p0.bk); p.s = batch_ptr(p0.s, p0.bk);
-    p.C = batch_ptr(p0.C, p0.bk); p.ws = batch_ptr(p0.ws, p0.bk);
+    p.C = batch_ptr(p0.C, p0.bk); p.ws = batch_ptr(p0.ws, p0.bk); p.sk_claim = batch_ptr(p0.sk_claim, p0.bk);
     return p;
 }
 
@@ -75,14 +85,6 @@ __device__ __forceinline__ void tile_coords(const GemmK& p, int t, int& ti, int&
     } else {
         ti = t / p.ntj; tj = t - ti * p.ntj;
     }
-}
-
-__device__ __forceinline__ long long wg_begin(long long g, long long total, int nwg) {
-    return (g * total) / nwg;
-}
-// workgroup that owns k-tile iteration `it`
-__device__ __forceinline__ int wg_owner(long long it, long long total, int nwg) {
-    return (int)(((it + 1) * (long long)nwg - 1) / total);
 }
 
 
@@ -187,100 +189,72 @@ __device__ __forceinline__ void tile_store(double* cb, long long ldc, const d4 (
     const int srow = tid >> 3;  /* staging: 32 rows per pass, 8 lanes per 128-B row segment */ \
     const int scol = (tid & 7) * 2;
 
-// A.D.A^T (also usable unscaled): data-parallel + stream-K hybrid.
-//   phase 1: the first ntiles_dp = floor(ntiles/nwg)*nwg tiles, one whole tile per workgroup per
-//            round.  Every workgroup walks k from 0 in lockstep, so the ~64 workgroups of an XCD
-//            (one 8x8 super-block of tiles) hit each other's A panels in that XCD's L2.
-//   phase 2: the remaining tiles' k-tile iterations are split evenly over all workgroups
-//            (stream-K): the tail that would otherwise leave most CUs idle.  A workgroup's partial
-//            first/last tile goes to a slab; gemm_nt_fixup_kernel adds the slabs in workgroup order.
-template <bool SCALE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_streamk_kernel(const GemmK p0) {
-    if (batch_done(p0.bk)) return;
-    const GemmK p = batch_shift(p0);
-    __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
-    TILE_THREAD_IDS
-    // batch in XCD-major layout: the workgroup's index inside its LP is blockIdx.y and the LP already sits on one XCD
-    const int g = p.bk.xcd_major ? (int)blockIdx.y : xcd_remap(blockIdx.x, gridDim.x);
-    const int KT = p.KT;
-    const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
-
-    for (int tile = g; tile < ntiles_dp; tile += p.nwg) {
-        int ti, tj;
-        tile_coords(p, tile, ti, tj);
-        d4 acc[4][4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
-        tile_mainloop<SCALE, 4, 4>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                                   p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, 0, KT, acc, srow,
-                                   scol, wr, wc, fr, fq);
-        double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 64 + fr);
-        tile_store<4, 4>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj && wr == wc,
-                         ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
-    }
-
-    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
-    long long it = wg_begin(g, total, p.nwg);
-    const long long end = wg_begin(g + 1, total, p.nwg);
-    bool first = true;
-    while (it < end) {
-        const int rt = (int)(it / KT);                       // remainder-tile index
-        const int kb = (int)(it - (long long)rt * KT);
-        const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
-        int ti, tj;
-        tile_coords(p, ntiles_dp + rt, ti, tj);
-        d4 acc[4][4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
-        tile_mainloop<SCALE, 4, 4>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                                   p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow,
-                                   scol, wr, wc, fr, fq);
-        if (kb == 0 && ke == KT) {
-            double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 64 + fr);
-            tile_store<4, 4>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj && wr == wc,
-                             ti * TILE + wr * 64 + fq, p.diag_pad_from, fr, fq);
-        } else {
-            double* sb0 = p.ws + ((long long)(2 * g + (first ? 0 : 1))) * (TILE * TILE) +
-                          (wr * 64 + fq) * TILE + wc * 64 + fr;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nj = 0; nj < 4; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
-        }
-        it += ke - kb;
-        first = false;
-    }
+// ---------------------------------------------------------------------------------------------------------
+// A.D.A^T kernel.  128x128 workgroup tile, 512 threads = 2x4 waves of 64x32 (4x2 MFMA tiles, 32 fp64
+// accumulators per lane), <= 128 VGPRs, so TWO such workgroups = 4 waves per SIMD are resident per CU.
+// Why 8 waves: with 2 waves per SIMD (the first version: 4 waves of 64x64 per workgroup) a wave's non-MFMA phase of a
+// k-tile (issue the prefetch, ds_read the fragments, scale + ds_write the next k-tile, barrier: ~4000 cycles under
+// contention, s_memtime stamps) is as long as its partner's MFMA phase (64 x 64 cycles), so the two can only just
+// cover each other (measured 87 % MFMA-busy); with 4 waves per SIMD each wave issues 32 MFMAs per k-tile and has
+// three partners' 6144 cycles of cover (93 %).
+//
+// chunk_end(q) is called when the k-tile that ends chunk q (kc k-tiles, counted from k-tile 0) has been
+// accumulated and more k-tiles follow: the caller flushes and clears the accumulators there, while the software
+// pipeline (next k-tile already in LDS) keeps running.
+// Addressing: buffer loads.  A tile's row panel is one buffer resource (wave-uniform origin in SGPRs), the k advance
+// and the +64-row step go into the scalar offset, and a lane contributes ONE 32-bit byte offset (its staging row and
+// column): the five loads of a k-tile cost one VGPR of addresses instead of ten.  At 128 VGPRs per wave (4 waves per
+// SIMD) every register the compiler spills inside this loop puts an `s_waitcnt vmcnt(0)` in front of the prefetch it
+// has just issued.  (A panel of 128 rows must stay below 4 GiB: ld < 4M columns, checked at launch.)
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ d2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)voff, (int)soff, 0);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 8-wave form of the same 128x128 workgroup tile: 512 threads = 2x4 waves of 64x32 (4x2 MFMA tiles, 32 fp64
-// accumulators per lane), <= 128 VGPRs, so TWO such workgroups = 4 waves per SIMD are resident per CU.
-// Why: with 2 waves per SIMD a wave's non-MFMA phase of a k-tile (issue the prefetch, ds_read the fragments,
-// scale + ds_write the next k-tile, barrier: ~4000 cycles under contention, s_memtime stamps) is as long as its
-// partner's MFMA phase (64 x 64 cycles), so the two can only just cover each other (measured 87 % MFMA-busy);
-// with 4 waves per SIMD each wave issues 32 MFMAs per k-tile and has three partners' 6144 cycles of cover.
-// Same operands, LDS image, stream-K split, slabs and fix-up as gemm_nt_streamk_kernel.
-template <bool SCALE>
-__device__ __forceinline__ void tile_mainloop_w8(double (*ldsA)[TILE][LDS_STRIDE], double (*ldsB)[TILE][LDS_STRIDE],
-                                                 const double* __restrict__ Pp, long long ldp,
-                                                 const double* __restrict__ Qp, long long ldq,
-                                                 const double* __restrict__ s, int kb, int ke, d4 (&acc)[4][2],
-                                                 int srow, int scol, int wr, int wc, int fr, int fq) {
+// Chunk phase of tile t: 0 (common boundaries kc, 2 kc, ...).  A per-tile phase ((t mod 64)/16 * kc/4, so that the
+// two workgroups of a CU flush half a chunk apart) was measured and dropped: the data-parallel workgroups flushing
+// together is not what a flush costs (C3, kc = 16: 2.51 ms with the phases, 2.57 without; the lockstep batch lost
+// 10 % to the extra short chunks).  Kept as a function so that a chunking stays a property of the tile alone.
+__device__ __forceinline__ int chunk_phase(int, int) { return 0; }
+// chunk q of a tile with phase o: k-tiles [q == 0 ? 0 : o + (q-1) kc, o + q kc), clipped to KT (q = 0 is empty for o = 0)
+__device__ __forceinline__ void chunk_range(int o, int kc, int q, int KT, int& kb, int& ke) {
+    kb = q == 0 ? 0 : o + (q - 1) * kc;
+    ke = o + q * kc;
+    if (ke > KT) ke = KT;
+    if (kb > KT) kb = KT;
+}
+
+// One pass over the k-tiles [kb, ke) of a tile, in chunks that end at o + j*kc k-tiles (kc == 0: one chunk).
+// The software pipeline (next k-tile prefetched into registers while the current one is multiplied out of LDS) runs
+// across chunk boundaries; the hot inner loop is the plain k-tile loop and the chunk logic lives around it:
+//   touch(first)  at the start of a chunk's last k-tile: may issue loads that pull the C tile towards L2
+//   flush(first)  after a chunk's last k-tile: stores / adds the accumulators (the caller's business); the
+//                 accumulators restart from zero if more chunks follow.
+template <bool SCALE, typename FL, typename TC>
+__device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], double (*ldsB)[TILE][LDS_STRIDE],
+                                             __amdgpu_buffer_rsrc_t Pr, unsigned p64, __amdgpu_buffer_rsrc_t Qr, unsigned q64,
+                                             __amdgpu_buffer_rsrc_t Sr, unsigned offP, unsigned offQ, unsigned offS,
+                                             int kb, int ke, d4 (&acc)[4][2],
+                                             int srow, int scol, int wr, int wc, int fr, int fq, int kc, int o, FL&& flush,
+                                             TC&& touch) {
     d2 sa[2], sb[2], sv = (d2){1.0, 1.0};
     auto gload = [&](int kt) {
-        const long long ko = (long long)kt * BK;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) sa[r] = *(const d2*)(Pp + (long long)(64 * r) * ldp + ko);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) sb[r] = *(const d2*)(Qp + (long long)(64 * r) * ldq + ko);
-        if (SCALE) sv = *(const d2*)(s + ko + scol);
+        const unsigned ko = (unsigned)kt * (unsigned)(BK * sizeof(double));
+        if (SCALE) sv = buf_load_d2(Sr, offS, ko);
+        sa[0] = buf_load_d2(Pr, offP, ko);
+        sa[1] = buf_load_d2(Pr, offP, ko + p64);
+        sb[0] = buf_load_d2(Qr, offQ, ko);
+        sb[1] = buf_load_d2(Qr, offQ, ko + q64);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -288,13 +262,7 @@ __device__ __forceinline__ void tile_mainloop_w8(double (*ldsA)[TILE][LDS_STRIDE
 #pragma unroll
         for (int r = 0; r < 2; ++r) *(d2*)&ldsB[buf][srow + 64 * r][scol] = SCALE ? sb[r] * sv : sb[r];
     };
-    gload(kb);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kb; kt < ke; ++kt) {
-        const bool more = kt + 1 < ke;
-        if (more) gload(kt + 1);
+    auto mfma_ktile = [&](int cur) {
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
             d2 a[4], b[2];
@@ -312,20 +280,60 @@ __device__ __forceinline__ void tile_mainloop_w8(double (*ldsA)[TILE][LDS_STRIDE
                         acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(2);   // the short non-MFMA phase goes first: it is what the partners wait for
+    };
+    gload(kb);
+    lstore(0);
+    __syncthreads();
+    int cur = 0, kt = kb;
+    bool first = true;
+    while (kt < ke) {
+        int ce = ke;                                       // end of this chunk
+        if (kc > 0) { const int e = kt < o ? o : o + ((kt - o) / kc + 1) * kc; ce = e < ke ? e : ke; }
+        for (; kt < ce - 1; ++kt) {                        // the hot loop
+            gload(kt + 1);
+            mfma_ktile(cur);
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+        const bool more = ce < ke;                         // last k-tile of the chunk
+        unsigned pf0 = 0, pf1 = 0;
+        touch(first, pf0, pf1);                            // (before the prefetch: whatever its addresses need reloaded must
+        if (more) gload(ce);                               //  not wait behind the loads issued here)
+        mfma_ktile(cur);
         if (more) lstore(cur ^ 1);
+        asm volatile("" :: "v"(pf0), "v"(pf1));            // the touch loads have landed (and their registers are free) from here
+        flush(first);
+        if (more) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+        first = false;
         __syncthreads();
         cur ^= 1;
+        kt = ce;
     }
     __builtin_amdgcn_s_setprio(0);
 }
 
+// Workgroup g of an LP:
+//   phase 1 (data-parallel): tiles g, g + nwg, ... of the first ntiles_dp = floor(ntiles/nwg)*nwg tiles, whole k-range
+//            each.  Every workgroup walks k from 0 in lockstep, so the ~64 workgroups of an XCD (one 8x8 super-block
+//            of tiles) hit each other's A panels in that XCD's L2.  With a canonical chunk (p.kc) the accumulators
+//            are added into the C tile at every chunk boundary and restart from zero.
+//   phase 2 (stream-K): the remaining tiles' k-range in chunks (p.kc, or SK_CHUNK k-tiles), claimed through one
+//            device word per LP: the data-parallel tiles do not all finish together (stamps at C3: 1876 .. 2025 us
+//            after launch), so chunks go to whoever is free.  Slab c holds chunk c; gemm_nt_fixup_kernel adds a
+//            tile's slabs in chunk order -- the same sums in the same order as phase 1's flushes.
 template <bool SCALE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_streamk_w8_kernel(const GemmK p0) {
     if (batch_done(p0.bk)) return;
     const GemmK p = batch_shift(p0);
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves: 64 rows x 32 columns each
     const int fr = lane & 15, fq = lane >> 4;
     const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
@@ -338,81 +346,99 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
     };
+    // C tile (ti, tj) as a buffer; this lane's element of MFMA block (mi, nj), register r sits at
+    //   offC + ((mi*16 + 4r)*ldc + nj*16) * 8   (wave-uniform second term)
+    const unsigned rowC = (unsigned)(p.ldc * (long long)sizeof(double));
+    const unsigned offC = (unsigned)(wr * 64 + fq) * rowC + (unsigned)((wc * 32 + fr) * sizeof(double));
+    auto c_rsrc = [&](int ti, int tj) { return make_rsrc(p.C + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC); };
     auto store_tile = [&](const d4 (&acc)[4][2], int ti, int tj) {
         double* cb = p.C + (long long)(ti * TILE + wr * 64 + fq) * p.ldc + (tj * TILE + wc * 32 + fr);
         tile_store<4, 2>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj, ti * TILE + wr * 64 + fq,
                          p.diag_pad_from, fr, fq, wc * 32 - wr * 64);
     };
+    // C tile += chunk sum (canonical order: alpha == 1, beta == 0).  Two rounds of 16 values per lane: the registers of
+    // the staging and fragment values, dead at this point, hold the C values on their way in.
+    auto add_tile = [&](const d4 (&acc)[4][2], int ti, int tj) {
+        const __amdgpu_buffer_rsrc_t cr = c_rsrc(ti, tj);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double cv[2][4][2];
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        cv[m2][r][nj] = buf_load_d(cr, offC, (unsigned)((2 * h + m2) * 16 + 4 * r) * rowC + nj * 128);
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        buf_store_d(cr, offC, (unsigned)((2 * h + m2) * 16 + 4 * r) * rowC + nj * 128,
+                                    cv[m2][r][nj] + acc[2 * h + m2][nj][r]);
+        }
+    };
+    // Touches every 128-B line of this wave's 64 x 32 part of the C tile (lane l: row l, columns 0 and 16), one k-tile
+    // before add_tile reads it: the tile was written a chunk ago and has left the L2 since (A streams through it), so
+    // the flush would otherwise pay two memory round trips (~6.5 us per flush measured, ~1.5 with the lines in L2).
+    auto touch_tile = [&](int ti, int tj, unsigned& pf0, unsigned& pf1) {
+        const __amdgpu_buffer_rsrc_t cr = c_rsrc(ti, tj);
+        const unsigned off = (unsigned)(wr * 64 + lane) * rowC + (unsigned)(wc * 32 * sizeof(double));
+        pf0 = __builtin_amdgcn_raw_buffer_load_b32(cr, (int)off, 0, 0);
+        pf1 = __builtin_amdgcn_raw_buffer_load_b32(cr, (int)off, 128, 0);
+    };
+    const unsigned rowP = (unsigned)(p.ldp * (long long)sizeof(double)), rowQ = (unsigned)(p.ldq * (long long)sizeof(double));
+    const unsigned offP = (unsigned)srow * rowP + (unsigned)(scol * sizeof(double));
+    const unsigned offQ = SCALE ? offP : (unsigned)srow * rowQ + (unsigned)(scol * sizeof(double));   // A.D.A^T: P = Q = A
+    const unsigned offS = (unsigned)(scol * sizeof(double));
+    const unsigned p64 = 64u * rowP, q64 = 64u * rowQ;
+    auto p_rsrc = [&](int ti) { return make_rsrc(p.P + (long long)(ti * TILE) * p.ldp, (unsigned)TILE * rowP); };
+    auto q_rsrc = [&](int tj) { return make_rsrc(p.Q + (long long)(tj * TILE) * p.ldq, (unsigned)TILE * rowQ); };
+    const __amdgpu_buffer_rsrc_t Sr = make_rsrc(SCALE ? p.s : p.P, (unsigned)KT * (unsigned)(BK * sizeof(double)));
     for (int tile = g; tile < ntiles_dp; tile += p.nwg) {
         int ti, tj;
         tile_coords(p, tile, ti, tj);
         d4 acc[4][2];
         zero(acc);
-        tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                                p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, 0, KT, acc, srow, scol, wr,
-                                wc, fr, fq);
-        store_tile(acc, ti, tj);
+        tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq,
+                            p.kc, chunk_phase(tile, p.kc), [&](bool first) { if (first) store_tile(acc, ti, tj); else add_tile(acc, ti, tj); },
+                            [&](bool first, unsigned& pf0, unsigned& pf1) { if (!first) touch_tile(ti, tj, pf0, pf1); });
     }
-    if (p.sk_claim) {
-        // Dynamic stream-K: the remainder tiles' k-ranges in chunks of SK_CHUNK k-tiles, claimed through one device word.
-        // The static split below hands every workgroup exactly one such chunk (at C3: 16 tiles x 512 k-tiles over 512
-        // workgroups), but the data-parallel tiles do not all finish together (stamps: 1876 .. 2025 us), so the static
-        // version ends 67 us after the slowest of them; claimed chunks go to whoever is free.  Slab c holds chunk c and the
-        // fix-up adds a tile's slabs in chunk order: same partial sums, same order, same bits as the static split.
-        __shared__ int s_claim;
-        const int cpt = KT / SK_CHUNK, nchunks = (p.ntiles - ntiles_dp) * cpt;
-        for (;;) {
-            if (tid == 0) s_claim = (int)atomicAdd(p.sk_claim, 1u);
-            __syncthreads();
-            const int ch = s_claim;
-            __syncthreads();
-            if (ch >= nchunks) break;
-            const int rt = ch / cpt, kb = (ch - rt * cpt) * SK_CHUNK;
-            int ti, tj;
-            tile_coords(p, ntiles_dp + rt, ti, tj);
-            d4 acc[4][2];
-            zero(acc);
-            tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                                    p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, kb + SK_CHUNK, acc, srow,
-                                    scol, wr, wc, fr, fq);
-            double* sb0 = p.ws + (long long)ch * (TILE * TILE) + (wr * 64 + fq) * TILE + wc * 32 + fr;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int nj = 0; nj < 2; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
-        }
-        return;
-    }
-    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
-    long long it = wg_begin(g, total, p.nwg);
-    const long long end = wg_begin(g + 1, total, p.nwg);
-    bool first = true;
-    while (it < end) {
-        const int rt = (int)(it / KT);
-        const int kb = (int)(it - (long long)rt * KT);
-        const int ke = (int)((long long)(KT - kb) < (end - it) ? KT : kb + (end - it));
+    if (ntiles_dp == p.ntiles) return;
+    __shared__ int s_claim;
+    const int ch_tiles = p.kc > 0 ? p.kc : SK_CHUNK;
+    const int cpt = (KT + ch_tiles - 1) / ch_tiles + (p.kc > 0 ? 1 : 0);   // chunk slots per tile (phased tiles: one more)
+    const int nchunks = (p.ntiles - ntiles_dp) * cpt;
+    for (;;) {
+        if (tid == 0) s_claim = (int)atomicAdd(p.sk_claim, 1u);
+        __syncthreads();
+        const int ch = __builtin_amdgcn_readfirstlane(s_claim);
+        __syncthreads();
+        if (ch >= nchunks) break;
+        const int rt = ch / cpt, q = ch - rt * cpt;
+        int kb, ke;
+        if (p.kc > 0) chunk_range(chunk_phase(ntiles_dp + rt, p.kc), p.kc, q, KT, kb, ke);
+        else { kb = q * SK_CHUNK; ke = kb + SK_CHUNK < KT ? kb + SK_CHUNK : KT; }
+        if (kb >= ke) continue;                                             // an empty slot
         int ti, tj;
         tile_coords(p, ntiles_dp + rt, ti, tj);
         d4 acc[4][2];
         zero(acc);
-        tile_mainloop_w8<SCALE>(ldsA, ldsB, p.P + (long long)(ti * TILE + srow) * p.ldp + scol, p.ldp,
-                                p.Q + (long long)(tj * TILE + srow) * p.ldq + scol, p.ldq, p.s, kb, ke, acc, srow, scol, wr,
-                                wc, fr, fq);
-        if (kb == 0 && ke == KT) {
-            store_tile(acc, ti, tj);
-        } else {
-            double* sb0 = p.ws + ((long long)(2 * g + (first ? 0 : 1))) * (TILE * TILE) + (wr * 64 + fq) * TILE + wc * 32 + fr;
+        tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq,
+                            0, 0, [&](bool) {
+            if (cpt == 1) { store_tile(acc, ti, tj); return; }   // the chunk is the whole tile
+            const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(p.ws + (long long)ch * (TILE * TILE), (unsigned)(TILE * TILE * sizeof(double)));
+            const unsigned offW = (unsigned)(((wr * 64 + fq) * TILE + wc * 32 + fr) * sizeof(double));
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int nj = 0; nj < 2; ++nj) sb0[(mi * 16 + 4 * r) * TILE + nj * 16] = acc[mi][nj][r];
-        }
-        it += ke - kb;
-        first = false;
+                    for (int nj = 0; nj < 2; ++nj)
+                        buf_store_d(wr_, offW, (unsigned)(((mi * 16 + 4 * r) * TILE + nj * 16) * sizeof(double)), acc[mi][nj][r]);
+        }, [](bool, unsigned&, unsigned&) {});
     }
 }
 
@@ -540,32 +566,31 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_grouped64_kernel(const GemmTil
     tile_store<2, 2>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
 }
 
-// Adds the partial slabs of every stream-K (remainder) tile whose k-range was split, in workgroup
-// order.  grid = remainder tiles x FIX_SPLIT: a tile can have dozens of slabs, so its 16K elements are
-// spread over FIX_SPLIT workgroups (8 rows each) to keep this pass off the critical path.
+// Adds the chunk slabs of every stream-K (remainder) tile in chunk order.  grid = remainder tiles x FIX_SPLIT:
+// a tile can have dozens of slabs, so its 16K elements are spread over FIX_SPLIT workgroups (8 rows each) to
+// keep this pass off the critical path.
 constexpr int FIX_SPLIT = 16;
 __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
     if (batch_done(p0.bk)) return;
     const GemmK p = batch_shift(p0);
-    const int KT = p.KT;
     const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
     const int bx = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
-    const int rt = bx / FIX_SPLIT, chunk = bx % FIX_SPLIT;
-    const long long total = (long long)(p.ntiles - ntiles_dp) * KT;
-    const long long it0 = (long long)rt * KT, it1 = it0 + KT;
-    const bool dyn = p.sk_claim != nullptr;          // slabs [rt*cpt, (rt+1)*cpt), one per claimed chunk
-    const int cpt = KT / SK_CHUNK;
-    const int g_lo = dyn ? rt * cpt : wg_owner(it0, total, p.nwg), g_hi = dyn ? rt * cpt + cpt - 1 : wg_owner(it1 - 1, total, p.nwg);
-    if (g_lo == g_hi) return;  // one workgroup computed the whole tile and wrote it directly
+    const int rt = bx / FIX_SPLIT, part = bx % FIX_SPLIT;
+    const int ch_tiles = p.kc > 0 ? p.kc : SK_CHUNK;
+    const int cpt = (p.KT + ch_tiles - 1) / ch_tiles + (p.kc > 0 ? 1 : 0);   // slab slots [rt*cpt, (rt+1)*cpt), one per chunk
+    int q0 = 0, q1 = cpt;                                                      // the non-empty ones: [q0, q1)
+    if (p.kc > 0) {
+        const int o = chunk_phase(ntiles_dp + rt, p.kc);
+        if (o == 0) q0 = 1;
+        while (q1 > q0 + 1 && o + (q1 - 2) * p.kc >= p.KT) --q1;
+    }
     int ti, tj;
     tile_coords(p, ntiles_dp + rt, ti, tj);
     constexpr int PER = TILE * TILE / FIX_SPLIT;
-    for (int e = chunk * PER + threadIdx.x * 2; e < (chunk + 1) * PER; e += 512) {
-        d2 sum = (d2){0.0, 0.0};
-        for (int g = g_lo; g <= g_hi; ++g) {
-            const int slot = wg_begin(g, total, p.nwg) >= it0 ? 0 : 1;
-            sum += *(const d2*)(p.ws + (dyn ? (long long)g : (long long)(2 * g + slot)) * (TILE * TILE) + e);
-        }
+    const double* slab0 = p.ws + (long long)rt * cpt * (TILE * TILE);
+    for (int e = part * PER + threadIdx.x * 2; e < (part + 1) * PER; e += 512) {
+        d2 sum = *(const d2*)(slab0 + (long long)q0 * (TILE * TILE) + e);
+        for (int q = q0 + 1; q < q1; ++q) sum += *(const d2*)(slab0 + (long long)q * (TILE * TILE) + e);
         const int r = e / TILE, c = e - r * TILE;
         const int row = ti * TILE + r, col = tj * TILE + c;
         double* cp = p.C + (long long)row * p.ldc + col;
@@ -579,12 +604,32 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
     }
 }
 
+// Canonical chunk of the A.D.A^T contraction in k-tiles: 256 columns (the reference dgemm's KC) up to n = 4096, 512
+// columns up to n = 16384, 1024 above: a data-parallel tile's flush is a read-modify-write of its C tile that costs
+// ~10 us (C3: 2.27 / 2.33 / 2.55 ms per launch at 1024 / 512 / 256 columns, and 5.5e-7 / 1.2e-7 / 7.9e-8 / 6.3e-8 from
+// the planted vertex for one running sum / 1024 / 512 / 256).  LPIPM_ADAT_KC=<k-tiles> overrides it (measurement knob).
+int gemm_streamk_chunk(int KT) {
+    static const int forced = getenv("LPIPM_ADAT_KC") ? atoi(getenv("LPIPM_ADAT_KC")) : -1;
+    if (forced >= 0) return forced == 0 ? (KT > 0 ? KT : 1) : forced;
+    return KT <= 256 ? 16 : (KT <= 1024 ? 32 : 64);
+}
+// chunk slots per tile for a contraction of KT k-tiles (1: no chunking, the tile is one running sum)
+static int streamk_cpt(int KT) {
+    const int kc = gemm_streamk_chunk(KT);
+    return KT <= kc ? 1 : (KT + kc - 1) / kc + 1;
+}
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu) {
-    const long long total = (long long)ntiles * KT;
+    const int cpt = streamk_cpt(KT);
+    const long long units = (long long)ntiles * (cpt > 1 ? cpt - 1 : 1);   // (tile, chunk) work units
     long long nwg = 2LL * num_cu;              // 2 resident workgroups per CU
-    if (nwg > total / 8) nwg = total / 8;      // at least 8 k-tiles (one 128-deep slice) each
+    if (nwg > units) nwg = units;
     if (nwg < 1) nwg = 1;
     return (int)nwg;
+}
+size_t gemm_streamk_slabs(int ntiles, int KT, int nwg) {
+    const int cpt = streamk_cpt(KT);
+    const int nrem = ntiles - (ntiles / nwg) * nwg;
+    return cpt > 1 ? (size_t)nrem * cpt : 0;
 }
 
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
@@ -593,10 +638,11 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.C = a.C; k.ldc = a.ldc; k.KT = a.K / BK; k.alpha = a.alpha; k.beta = a.beta;
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg; k.bk = batch_k(a.batch);
-    k.sk_claim = nullptr;
+    k.sk_claim = a.sk_claim; k.kc = 0;
     const int B = a.batch.count;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
-    if (a.nwg == a.ntiles && !a.s && a.diag_pad_from < 0) {   // one whole tile per workgroup
+    if (!a.streamk) {   // one whole tile per workgroup
+        if (a.nwg != a.ntiles || a.s || a.diag_pad_from >= 0) return hipErrorInvalidValue;
         if (a.tile_edge == 64 && k.KT == 8)      hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<2, 2>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         else if (a.tile_edge == 32 && k.KT == 8) hipLaunchKernelGGL((gemm_nt_tile_k128_kernel<1, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         else if (a.tile_edge == 64) hipLaunchKernelGGL((gemm_nt_tile_kernel<2, 2>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
@@ -604,32 +650,30 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
         else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         return hipGetLastError();
     }
+    // A.D.A^T: canonical chunked summation (see the head of this file); alpha = 1, beta = 0 only
+    if (a.alpha != 1.0 || a.beta != 0.0 || !a.sk_claim) return hipErrorInvalidValue;
+    if (a.ldp >= (1 << 22) || a.ldq >= (1 << 22) || a.ldc >= (1 << 22)) return hipErrorInvalidValue;   // 128-row panels are 32-bit buffers
+    if (a.s && a.ldp != a.ldq) return hipErrorInvalidValue;    // the scaled form is A.D.A^T: both operands are A
+    k.kc = gemm_streamk_chunk(k.KT);
+    if (k.KT <= k.kc) k.kc = 0;              // short contraction: one running sum per tile (and SK_CHUNK >= KT: whole tiles)
+    if (k.kc == 0 && k.KT > SK_CHUNK) return hipErrorInvalidValue;
+    const int cpt = streamk_cpt(k.KT);
+    const int nrem = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
+    if (nrem > 0) {
+        if (cpt > 1 && !a.ws) return hipErrorInvalidValue;
+        hipError_t em = B == 1 ? hipMemsetAsync(a.sk_claim, 0, sizeof(unsigned int), st)
+                               : hipMemset2DAsync(a.sk_claim, (size_t)a.batch.stride, 0, sizeof(unsigned int), (size_t)B, st);
+        if (em != hipSuccess) return em;
+    }
     // a batch of a multiple of 8 LPs: one LP per XCD at a time (see BatchK)
     const bool xm = B >= 8 && B % 8 == 0;
     k.bk.xcd_major = xm ? 1 : 0;
     const dim3 grid = xm ? dim3(8, a.nwg, B / 8) : dim3(a.nwg, 1, B);
-    static const bool w4 = getenv("LPIPM_ADAT_W4") != nullptr;   // measurement knob: the 4-wave form (scripts/adat_ab.py)
-    static const bool sk_static = getenv("LPIPM_SK_STATIC") != nullptr;   // measurement knob: static stream-K split
-    // dynamic claiming of the remainder chunks: single LP, 8-wave kernel, a data-parallel phase exists, chunks divide K
-    const int nrem_ = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
-    if (a.sk_claim && !w4 && !sk_static && B == 1 && a.ntiles >= a.nwg && nrem_ > 0 && k.KT % SK_CHUNK == 0 && k.KT > SK_CHUNK &&
-        nrem_ * (k.KT / SK_CHUNK) <= 2 * a.nwg) {
-        hipError_t em = hipMemsetAsync(a.sk_claim, 0, sizeof(unsigned int), st);
-        if (em != hipSuccess) return em;
-        k.sk_claim = a.sk_claim;
-    }
-    if (a.s && !w4) hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<true>, grid, dim3(512), 0, st, k);
-    else if (a.s)   hipLaunchKernelGGL(gemm_nt_streamk_kernel<true>, grid, dim3(256), 0, st, k);
-    else if (!w4)   hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<false>, grid, dim3(512), 0, st, k);
-    else            hipLaunchKernelGGL(gemm_nt_streamk_kernel<false>, grid, dim3(256), 0, st, k);
+    if (a.s) hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<true>, grid, dim3(512), 0, st, k);
+    else     hipLaunchKernelGGL(gemm_nt_streamk_w8_kernel<false>, grid, dim3(512), 0, st, k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // remainder tiles: a split exists unless every workgroup boundary falls on a tile boundary
-    const int nrem = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
-    const long long total = (long long)nrem * k.KT;
-    bool split = false;
-    for (int g = 1; g < a.nwg && !split; ++g) split = ((g * total) / a.nwg) % k.KT != 0;
-    if (split || k.sk_claim) {
+    if (nrem > 0 && cpt > 1) {
         hipLaunchKernelGGL(gemm_nt_fixup_kernel, xm ? dim3(8, nrem * FIX_SPLIT, B / 8) : dim3(nrem * FIX_SPLIT, 1, B), dim3(256), 0,
                            st, k);
         e = hipGetLastError();

@@ -92,17 +92,22 @@ struct GemmArgs {
     int           ntj;          // rectangular: number of tile columns
     const int2*   tile_list;    // nullable: explicit (ti,tj) order (device pointer)
     int           diag_pad_from;// rows/cols >= this on the diagonal are written as 1.0 (-1: off)
-    double*       ws;           // stream-K partial slabs: 2 per workgroup, TILE*TILE doubles each
-    int           nwg;          // workgroups launched (== grid); ntiles*KT split evenly
-    unsigned int* sk_claim;     // nullable (single LP, 8-wave kernel): a zeroed device word -> the k-chunks of the stream-K
-                                //   remainder tiles are claimed dynamically (workgroups that finish their data-parallel
-                                //   tile early take more of them); slabs are indexed by chunk, so the sums do not change
+    int           streamk;      // 1: the A.D.A^T kernel (data-parallel tiles + claimed stream-K chunks, canonical chunked
+                                //    summation; alpha = 1, beta = 0); 0: whole-tile kernels, nwg == ntiles
+    double*       ws;           // stream-K chunk slabs: gemm_streamk_slabs() tiles of TILE*TILE doubles
+    int           nwg;          // workgroups launched per LP
+    unsigned int* sk_claim;     // stream-K: the device word through which the chunks of the remainder tiles are claimed
+                                //   (workgroups that finish their data-parallel tiles early take more of them); slabs are
+                                //   indexed by chunk, so the sums do not depend on who computed what
     int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
     Batch         batch;        // lockstep batch (every pointer above except tile_list is per LP)
 };
-// Launches the main kernel and, when the k-range of a tile is split over workgroups, the
-// deterministic fix-up pass.  ws must hold 2*nwg slabs when nwg != ntiles.
+// Launches the main kernel and, when tiles are split into stream-K chunks, the deterministic fix-up pass.
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st);
+// stream-K geometry: canonical chunk (k-tiles) for a contraction of KT k-tiles, workgroup count for ntiles x KT
+// work on num_cu CUs, and the number of TILE x TILE slabs ws must hold for a given workgroup count
+int gemm_streamk_chunk(int KT);
+size_t gemm_streamk_slabs(int ntiles, int KT, int nwg);
 // One output tile (128x128, or 64x64 with edge = 64) of a grouped launch: C = alpha * P[0:E, kb:ke) . Q[0:E, kb:ke)^T
 // (k-range in units of BK), each tile with its own operands.
 struct GemmTileDesc {

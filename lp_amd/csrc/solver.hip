@@ -286,6 +286,12 @@ static std::vector<int2> adat_tile_order(int nt) {
 // Output tile edge of the inverse-merge GEMMs: 64 (a stage of one LP is a few dozen latency-bound tiles: factorisation
 // 422 -> 358 us at m = 512, 719 -> 547 at 1024, 2556 -> 2398 at 4096; a batch that fills the chip is indifferent).
 // LPIPM_MERGE_EDGE=128 restores the 128x128 tiles (measurement knob, scripts/potrf_sizes.py).
+// Width of the diagonal super-blocks whose explicit inverses feed the triangular solves.  LPIPM_SUPER=<multiple of 128>
+// overrides it (measurement knob: accuracy / speed A-B of the solve path).
+static int super_for(int B) {
+    if (const char* e = getenv("LPIPM_SUPER")) { const int w = atoi(e); if (w >= NB && w % NB == 0 && w <= 4096) return w; }
+    return B >= 8 ? 512 : SUPER;
+}
 static int merge_edge_for(int) {
     if (const char* e = getenv("LPIPM_MERGE_EDGE")) return atoi(e) == 128 ? 128 : 64;
     return 64;
@@ -314,13 +320,13 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     c->M = ar.take<double>(mp * mp);
     // a batch that fills the chip is flop-bound: the last doubling level of the inverse (1024) costs more than the
     // two extra solve steps it saves
-    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, c->B >= 8 ? 512 : SUPER, merge_edge_for(c->B)));
+    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->B), merge_edge_for(c->B)));
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
     c->sk_claim = ar.take<unsigned int>(1);
-    // stream-K slabs of A.D.A^T: only when a tile's k-range can be split over workgroups
-    c->ws = ar.take<double>(c->adat_nwg == c->ntiles ? 1 : (size_t)2 * c->adat_nwg * TILE * TILE);
+    // stream-K chunk slabs of A.D.A^T (tiles that do not divide over the workgroups)
+    c->ws = ar.take<double>(gemm_streamk_slabs(c->ntiles, c->npa / BK, c->adat_nwg) * TILE * TILE);
     return LPIPM_OK;
 }
 
@@ -487,7 +493,7 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     g.P = c->A; g.ldp = c->npa; g.Q = c->A; g.ldq = c->npa; g.s = c->va.dinv;
     g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
-    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt; g.sk_claim = c->sk_claim;
+    g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt; g.sk_claim = c->sk_claim; g.streamk = 1;
     hipError_t e = launch_gemm_nt(g, c->st);
     if (e != hipSuccess) return e;
     return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
@@ -1047,12 +1053,12 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->ktau, (size_t)mp, c->st));
     Arena measure;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st, SUPER, merge_edge_for(1)));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st, super_for(1), merge_edge_for(1)));
     char* kar = nullptr;
     LP_TRY(dalloc(c->kallocs, nullptr, &kar, measure.off + 256, c->st));   // zeroed
     Arena real;
     real.base = kar;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st, SUPER, merge_edge_for(1)));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st, super_for(1), merge_edge_for(1)));
     c->kmp = mp;
     return LPIPM_OK;
 }

@@ -167,8 +167,9 @@ def _step_size(x, z, tau, kappa, d, alpha0):
     return min(1.0, ax, at, az, ak) * alpha0
 
 
-def solve(A, b, c, c0=0.0, opts: Opts | None = None) -> Result:
-    """mod.rs:199-240 + :161-168 on the slack-form problem."""
+def solve(A, b, c, c0=0.0, opts: Opts | None = None, trace: list | None = None) -> Result:
+    """mod.rs:199-240 + :161-168 on the slack-form problem.  trace (tests / diagnostics): receives a copy of the
+    iterate (x, y, z, tau, kappa) at the start of every iteration."""
     opts = opts or Opts()
     if not (0.0 < opts.alpha0 < 1.0) or not (opts.tol > 0.0):                 # mod.rs:118-128
         return Result(INVALID_PARAMETER, None, None, 0)
@@ -184,6 +185,8 @@ def solve(A, b, c, c0=0.0, opts: Opts | None = None) -> Result:
     log = []
     status, it = ITERATION_LIMIT, 0
     for it in range(1, opts.max_iter + 1):                                    # mod.rs:213
+        if trace is not None:
+            trace.append((x.copy(), y.copy(), z.copy(), tau, kappa))
         # get_delta, feasible_point.rs:110-152
         gamma = 1.0 if ip else 0.0
         eta = 1.0 if ip else 1.0 - gamma

@@ -1,0 +1,68 @@
+"""Golden vectors for BASELINE config C4's real members: planted dense LPs 1024x2048, seeds 0..255
+(SURVEY.md 8d generator, lp_amd/csrc/synth.cpp), solved by the C oracle (oracle/oracle_ipm.c) with the
+reference's default options.
+
+For every seed the file holds the oracle's x_slack, fun, iteration count, its distance to the planted vertex,
+and the oracle's OWN rounding-noise floor on that LP: the same LP with its columns permuted (a mathematically
+identical problem that only changes summation orders, SURVEY.md 8d "FP-noise floor") solved again, and
+|x - x_permuted|_inf recorded.  The GPU parity tests require the oracle's iteration count and
+|x_gpu - x_oracle|_inf <= max(1e-6, 10 * floor) per member.
+
+The reference itself cannot run here (Rust, no toolchain): these vectors come from the restatement, which the
+reference's known answers pin end to end (tests/test_oracle_golden.py).
+
+Run from the repo root:  python tests/golden/make_c4_members.py [--seeds 256] [--procs 8]
+"""
+import argparse
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+M, N = 1024, 2048
+
+
+def one(seed):
+    from lp_amd import synth
+    from oracle import capi as oracle
+    A, b, c, xstar = synth.planted_lp(seed, M, N)
+    r = oracle.solve(A, b, c, want_log=True)
+    perm = np.random.default_rng(1000 + seed).permutation(N)
+    r2 = oracle.solve(np.ascontiguousarray(A[:, perm]), b, np.ascontiguousarray(c[perm]), want_log=False)
+    x2 = np.empty(N)
+    x2[perm] = r2["x_slack"]
+    floor = float(np.abs(x2 - r["x_slack"]).max()) if r2["iterations"] == r["iterations"] else float("inf")
+    alphas = np.array([row[0] for row in r["log"]])
+    return (seed, r["status"], r["x_slack"], r["fun"], r["iterations"], float(np.abs(r["x_slack"] - xstar).max()),
+            floor, r2["iterations"], alphas)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=256)
+    ap.add_argument("--procs", type=int, default=8)
+    a = ap.parse_args()
+    with Pool(a.procs) as p:
+        rows = p.map(one, range(a.seeds), chunksize=1)
+    rows.sort(key=lambda r: r[0])
+    assert all(r[1] == 0 for r in rows), [r[0] for r in rows if r[1] != 0]
+    maxit = max(r[4] for r in rows)
+    alpha = np.full((len(rows), maxit), np.nan)
+    for i, r in enumerate(rows):
+        alpha[i, :len(r[8])] = r[8]
+    np.savez_compressed(os.path.join(HERE, "c4_members.npz"), m=M, n=N,
+                        seeds=np.array([r[0] for r in rows]), x_slack=np.stack([r[2] for r in rows]),
+                        fun=np.array([r[3] for r in rows]), iterations=np.array([r[4] for r in rows]),
+                        xstar_err=np.array([r[5] for r in rows]), floor=np.array([r[6] for r in rows]),
+                        iterations_permuted=np.array([r[7] for r in rows]), alpha=alpha)
+    fl = np.array([r[6] for r in rows])
+    print("members", len(rows), "iterations", np.bincount([r[4] for r in rows]), "floor median %.2e max %.2e; > 1e-7: %d"
+          % (np.median(fl), fl.max(), int((fl > 1e-7).sum())))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ KNOWN = [
 # expected x = 1 within 1e-10 (tests build it on the fly).
 
 PLANTED = [(0, 64, 128), (1, 100, 333), (0, 256, 512), (0, 512, 1024)]
-PLANTED_BIG = [(0, 4096, 8192)]
+PLANTED_BIG = [(0, 4096, 8192), (1, 4096, 8192), (2, 4096, 8192), (3, 4096, 8192)]
 
 
 def main():
@@ -47,6 +47,8 @@ def main():
         json.dump(dict(note="iterations = count observed with the oracle (SURVEY.md 4 lists the same)",
                        cases=KNOWN), f, indent=1)
     todo = PLANTED + (PLANTED_BIG if "--big" in sys.argv else [])
+    if "--only-big" in sys.argv:     # python tests/golden/make_golden.py --only-big <seed>   (one process per seed)
+        todo = [t for t in PLANTED_BIG if t[0] == int(sys.argv[sys.argv.index("--only-big") + 1])]
     for seed, m, n in todo:
         A, b, c, xstar = synth.planted_lp(seed, m, n)
         r = oracle.solve(A, b, c)
