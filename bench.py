@@ -11,8 +11,12 @@ Weak scaling: every rank owns ONE independent LP of the same shape (seed = rank)
 one per GPU with no data-path collective -- and the timed region ends with the single RCCL
 all-gather of the solutions.  value = IPM iterations of all ranks / max-over-ranks wall time.
 
-`--workload c4` (optional, not the default): BASELINE config 4 instead -- 32 independent 1024x2048 LPs per GPU as one
-lockstep batch with resident inputs, value in LP/s; same timing protocol, no roofline / cpu_baseline objects.
+`--workload c2` (optional): BASELINE config 2 -- one 512x1024 LP per GPU ("GEMV-bound, HBM roofline check"), same
+protocol; its `roofline` object is the HBM one: the passes over A (GEMV-N / GEMV-T), algorithmic bytes 8mn per pass /
+the average pass duration from HIP events on the solver's stream inside the timed region, against 8 TB/s.
+`--workload c4` (optional): BASELINE config 4 -- 32 independent 1024x2048 LPs per GPU as one lockstep batch with
+resident inputs, value in LP/s; same timing protocol; exits non-zero if a member is further than 1e-6 (or 10x its
+recorded oracle noise floor) from the committed oracle vector.
 
 Extra objects on the JSON line:
   roofline     : the dominant kernel (A.D.A^T, MFMA-bound): algorithmic flops m(m+1)n per launch /
@@ -20,9 +24,14 @@ Extra objects on the JSON line:
                  INSIDE the timed region (2 events per iteration, bracketing that kernel and its fix-up);
                  peak = 78.6 TFLOP/s dense fp64 MFMA.  The per-phase breakdown comes from one extra,
                  untimed solve with every phase bracketed.
-  cpu_baseline : rank 0, N == 1 only: the single-threaded C restatement of the reference
-                 (oracle/, kind "port") timed on this box's host for ONE IPM iteration of the same LP
-                 (every iteration performs the same operations, so 1 / t is its iterations/sec).
+  cpu_baseline : rank 0, N == 1 only: the single-threaded C restatement of the reference (oracle/, kind "port") timed
+                 on this box's host for the first TWO IPM iterations of the same LP (two runs, max_iter 1 and 2: the
+                 second iteration's time is the difference; the op count does not depend on the iterate), plus
+                 "strong": the NumPy/OpenBLAS transcription on all host cores (stand-in for the reference's
+                 `openblas-system` feature, Cargo.toml:23-24).  Baselines, not targets.
+  roofline.traffic / mfma_busy_pmc come from a separate rocprofv3 --pmc run (counters cannot be read from inside this
+                 process) whose summary is committed under profiles/ WITH a hash of lp_amd/csrc at collection time:
+                 they are reported only while that hash still matches the sources ("recorded, not measured in this run").
 """
 from __future__ import annotations
 
@@ -43,6 +52,55 @@ def emit(obj):
 
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (probe: lpipm_k_mfma_f64_probe ~76 TF/s)
+PEAK_HBM_GBS = 8000.0          # HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel / host sources of liblpipm.so (what a PMC summary under profiles/ is stamped with)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lp_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def cpu_baseline(A, b, c, m, n):
+    """The reference's CPU path, restated (oracle/), timed on this box's host cores on a bounded sample of the same LP.
+    port   : single-threaded C restatement with the reference's as-written op counts -- iterations 1 and 2
+             (the default backend is single-threaded: ndarray without rayon/blas, Cargo.toml:31-33);
+    strong : the NumPy/OpenBLAS transcription on all host cores (stand-in for `openblas-system`, Cargo.toml:23-24)."""
+    from oracle import capi as oracle                        # checker / baseline only
+    from oracle import oracle_np
+    big = m * n >= 1 << 24
+    t1 = time.perf_counter()
+    r1 = oracle.solve(A, b, c, 0.0, oracle.default_opts(max_iter=1), want_log=False)
+    r2 = oracle.solve(A, b, c, 0.0, oracle.default_opts(max_iter=2), want_log=False)
+    tc = time.perf_counter() - t1
+    it1 = r1["timing"]["total"]
+    it2 = r2["timing"]["total"] - it1
+    per_it = 0.5 * r2["timing"]["total"]
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    k = 3 if big else 6
+    t1 = time.perf_counter()
+    rs = oracle_np.solve(A, b, c, 0.0, oracle_np.Opts(max_iter=k))
+    ts = time.perf_counter() - t1
+    return {
+        "value": 1.0 / per_it, "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": f"IPM iterations 1 and 2 of the same {m}x{n} LP with the single-threaded C restatement of the reference "
+                  f"(as-written op counts): {it1:.2f} s and {it2:.2f} s ({tc:.1f} s of CPU work in two runs, max_iter 1 and 2); "
+                  f"the op count per iteration does not depend on the iterate",
+        "seconds_iteration_1": it1, "seconds_iteration_2": it2,
+        "phase_s_two_iterations": r2["timing"],
+        "strong": {"value": rs.iterations / rs.timing["total"], "unit": "iterations/s", "cores": ncores,
+                   "kind": "port-openblas",
+                   "sample": f"{rs.iterations} iterations of the same LP with the NumPy/SciPy (OpenBLAS, LAPACK dpotrf/dpotrs) "
+                             f"transcription on {ncores} host cores, {ts:.1f} s",
+                   "phase_s": rs.timing},
+    }
+
 
 
 def main():
@@ -53,10 +111,15 @@ def main():
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("c3", "c4"), default="c3",
-                    help="c3 (default, the BASELINE metric): one 4096x8192 LP per GPU; c4: a shard of 32 independent "
-                         "1024x2048 LPs per GPU as one lockstep batch (BASELINE config 4: 256 LPs over 8 GPUs)")
+    ap.add_argument("--workload", choices=("c3", "c2", "c4"), default="c3",
+                    help="c3 (default, the BASELINE metric): one 4096x8192 LP per GPU; c2: one 512x1024 LP per GPU (HBM "
+                         "roofline on the GEMV passes); c4: a shard of 32 independent 1024x2048 LPs per GPU as one lockstep "
+                         "batch (BASELINE config 4: 256 LPs over 8 GPUs)")
     args = ap.parse_args()
+    if args.workload == "c2":
+        args.m, args.n = 512, 1024
+        if args.steps == 5:
+            args.steps = 200           # a C2 solve is ~2 ms: keep the timed region near half a second
 
     # STDOUT carries exactly one line, the JSON result.  Libraries that print to file descriptor 1 on their own (RCCL's
     # version banner under NCCL_DEBUG=VERSION, warnings) are sent to stderr for the lifetime of the process.
@@ -116,10 +179,14 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    ctx.set_profiling(2)                                 # HIP events around the dominant kernel only (2 per
-                                                         # iteration), recorded on the solver's own stream
+    c2 = args.workload == "c2"
+    # HIP events recorded on the solver's own stream: c3 -- around the dominant kernel only (2 per iteration);
+    # c2 -- every phase (the GEMV passes are five separate intervals per iteration)
+    ctx.set_profiling(1 if c2 else 2)
     adat_ms = 0.0
     adat_launches = 0
+    gemv_ms = 0.0
+    gemv_passes = 0
     phase = {k: 0.0 for k in ("adat_ms", "potrf_ms", "trsv_ms", "gemv_ms", "vec_ms", "total_ms")}
     iters_local = 0
     barrier()
@@ -130,6 +197,8 @@ def main():
         pt = ctx.phase_times()
         adat_ms += pt["adat_ms"]
         adat_launches += pt["adat_launches"]
+        gemv_ms += pt["gemv_ms"]
+        gemv_passes += pt["gemv_passes"]
     barrier()
     dt = time.perf_counter() - t0
     # per-phase breakdown: one more solve with every phase bracketed by events, OUTSIDE the timed region
@@ -157,17 +226,43 @@ def main():
         flops_per_launch = float(m) * (m + 1) * n                     # lower triangle of A.D.A^T
         avg_ms = adat_ms / max(adat_launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run (counters
-        # cannot be read from inside this process); the committed summary is profiles/r01_adat_pmc.json.
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (counters cannot be read from inside this
+        # process).  The committed summary carries the hash of lp_amd/csrc it was collected with; a stale one is not used.
         traffic = None
         mfma_busy = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_adat_pmc.json")
-        if (m, n) == (4096, 8192) and os.path.exists(pmc_path):
+        pmc_note = "no PMC summary for this workload"
+        pmc_path = os.path.join(ROOT, "profiles", "r02_gemv_pmc.json" if c2 else "r02_adat_pmc.json")
+        if (m, n) in ((4096, 8192), (512, 1024)) and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            traffic = pmc.get("traffic_bytes_per_launch")
-            mfma_busy = pmc.get("mfma_busy_fraction")
+            if pmc.get("csrc_sha256") == csrc_hash():
+                traffic = pmc.get("traffic_bytes_per_launch")
+                mfma_busy = pmc.get("mfma_busy_fraction")
+                pmc_note = f"recorded by rocprofv3 --pmc ({os.path.relpath(pmc_path, ROOT)}), not measured in this run; kernel sources unchanged since"
+            else:
+                pmc_note = f"{os.path.relpath(pmc_path, ROOT)} was collected with other kernel sources (hash mismatch): not reported"
+        if c2:
+            bytes_per_pass = 8.0 * m * n                               # A once per pass (1 or 2 vectors ride along)
+            avg_ms = gemv_ms / max(gemv_passes, 1)
+            achieved = bytes_per_pass / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {"kernel": "gemv_n_kernel / gemv_t_kernel (passes over A: A.w and A^T.v, 1-2 vectors per pass)",
+                        "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_note": pmc_note,
+                        "algorithmic_bytes_per_launch": bytes_per_pass, "avg_launch_ms": avg_ms, "launches": gemv_passes,
+                        "note": "at this size a pass moves 4 MiB: its duration is the dependent-dispatch latency of a kernel, "
+                                "not bytes (DESIGN.md 3.4)"}
+        else:
+            roofline = {"kernel": "gemm_nt_streamk_w8_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
+                                  "v_mfma_f64_16x16x4_f64)",
+                        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                        "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                        "traffic_note": pmc_note,
+                        "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
+                        "mfma_busy_pmc": mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES share of the kernel's SIMD-cycles (same JSON)
+                        "avg_launch_ms": avg_ms, "launches": adat_launches,
+                        "flops_per_launch": flops_per_launch}
         out = {
-            "metric": "IPM iterations/sec, dense 4096x8192 fp64 LP",
+            "metric": f"IPM iterations/sec, dense {m}x{n} fp64 LP",
             "value": iters_total / dt_max,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -179,35 +274,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{'C3' if (m, n) == (4096, 8192) else 'custom'}: random dense planted LP m={m} n={n} fp64, one independent LP per GPU "
+            "config": {"workload": f"{'C3' if (m, n) == (4096, 8192) else ('C2' if (m, n) == (512, 1024) else 'custom')}: random dense planted LP m={m} n={n} fp64, one independent LP per GPU "
                                    f"(seed = rank), reference default options, A resident in HBM",
                        "m": m, "n": n, "iterations_per_solve": iters_local / args.steps,
                        "max_abs_err_vs_planted_optimum": err},
-            "roofline": {"kernel": "gemm_nt_streamk_w8_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
-                                   "v_mfma_f64_16x16x4_f64)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                                             "profiles/r01_adat_pmc.json)",
-                         "algorithmic_bytes_per_launch": 8.0 * m * n + 4.0 * m * m,
-                         "mfma_busy_pmc": mfma_busy,   # SQ_VALU_MFMA_BUSY_CYCLES share of the kernel's SIMD-cycles (same JSON)
-                         "avg_launch_ms": avg_ms, "launches": adat_launches,
-                         "flops_per_launch": flops_per_launch},
+            "roofline": roofline,
             "phase_ms_per_iteration": {k: v / phase_iters for k, v in phase.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import capi as oracle                        # checker / baseline only
-            o = oracle.default_opts(max_iter=1)
-            t1 = time.perf_counter()
-            r = oracle.solve(A, b, c, 0.0, o, want_log=False)
-            tc = time.perf_counter() - t1
-            out["cpu_baseline"] = {
-                "value": 1.0 / r["timing"]["total"], "unit": "iterations/s", "cores": 1, "kind": "port",
-                "sample": f"1 IPM iteration (the first) of the same {m}x{n} LP with the single-threaded C "
-                          f"restatement of the reference (as-written op counts); {tc:.1f} s of CPU work; "
-                          f"every iteration performs the same operations",
-                "phase_s": r["timing"],
-            }
+            out["cpu_baseline"] = cpu_baseline(A, b, c, m, n)
         emit(out)
     if dist is not None:
         dist.barrier()
@@ -216,14 +291,20 @@ def main():
 
 def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth):
     """BASELINE config 4: 32 independent 1024x2048 LPs per GPU (256 over 8), solved as ONE lockstep batch with the inputs
-    resident in HBM, then the single gather of the solutions.  value = LPs of all ranks / max-over-ranks wall time."""
+    resident in HBM; every x / tau goes device to device into the rank's packed block and ONE all-gather (RCCL) of those
+    blocks ends the step.  value = LPs of all ranks / max-over-ranks wall time.  The members are the seeds of the
+    committed oracle fixture (tests/golden/c4_members.npz): after the timed region every member of this rank is compared
+    with it and the process exits non-zero if one is beyond max(1e-6, 10 x its recorded oracle noise floor)."""
     import time
     per_rank, m, n = 32, 1024, 2048
-    probs = [synth.planted_lp(rank * per_rank + s, m, n) for s in range(per_rank)]
+    seeds = [rank * per_rank + s for s in range(per_rank)]
+    probs = [synth.planted_lp(s, m, n) for s in seeds]
     ctx = lp_amd.Context(local_rank)
     ctx.upload_lockstep([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs])   # untimed H2D
     opts = lp_amd.InteriorPoint.default().opts()
-    gathered = torch.zeros(world * per_rank * n, dtype=torch.float64, device=dev) if dist is not None else None
+    xs = torch.zeros((per_rank, n), dtype=torch.float64, device=dev)
+    gathered = torch.zeros((world * per_rank, n), dtype=torch.float64, device=dev) if dist is not None else None
+    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -231,11 +312,10 @@ def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth)
         torch.cuda.synchronize()
 
     def one_step():
-        res = ctx.solve_lockstep(opts)
+        res = ctx.solve_lockstep_device(opts, xs.data_ptr(), n)    # returns when the rows are in place
         if any(r[0] != 0 for r in res):
             raise RuntimeError("a member of the shard did not solve")
         if dist is not None:                              # the single RCCL gather of the batch's solutions
-            xs = torch.from_numpy(np.stack([r[1] for r in res]).reshape(-1)).to(dev)
             dist.all_gather_into_tensor(gathered, xs)
         return res
 
@@ -247,10 +327,25 @@ def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth)
         res = one_step()
     barrier()
     dt = time.perf_counter() - t0
-    its = sum(r[3] for r in res)
-    err = max(float(np.abs(r[1] - p[3]).max()) for r, p in zip(res, probs))
+    its = sum(r[2] for r in res)
+    x_host = xs.cpu().numpy()
+    err = max(float(np.abs(x_host[k] - p[3]).max()) for k, p in enumerate(probs))
+    # parity against the committed oracle vectors of exactly these members
+    parity = {"checked": False}
+    gold = os.path.join(ROOT, "tests", "golden", "c4_members.npz")
+    bad = []
+    if os.path.exists(gold):
+        g = np.load(gold)
+        if int(g["m"]) == m and int(g["n"]) == n and max(seeds) < len(g["seeds"]):
+            e = np.array([np.abs(x_host[k] - g["x_slack"][s]).max() for k, s in enumerate(seeds)])
+            bar = np.maximum(1e-6, 10.0 * g["floor"][seeds])
+            bad = [(int(s), float(e[k]), float(bar[k])) for k, s in enumerate(seeds)
+                   if e[k] > bar[k] or res[k][2] != int(g["iterations"][s])]
+            parity = {"checked": True, "members": len(seeds), "max_abs_err_vs_oracle": float(e.max()),
+                      "median_abs_err_vs_oracle": float(np.median(e)), "tolerance": "max(1e-6, 10 x oracle noise floor) per member",
+                      "failed_members": bad}
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, float(len(bad))], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     if rank == 0:
@@ -259,11 +354,15 @@ def bench_c4(args, rank, local_rank, world, dist, dev, np, torch, lp_amd, synth)
             "unit": "LP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4: {world * per_rank} independent planted LPs m={m} n={n} fp64, {per_rank} per GPU as one lockstep batch, "
-                                   "inputs resident in HBM, one all-gather of the solutions",
-                       "iterations_per_lp": its / per_rank, "max_abs_err_vs_planted_optimum": err}})
+                                   "inputs resident in HBM, solutions device to device into the packed block, one all-gather",
+                       "iterations_per_lp": its / per_rank, "max_abs_err_vs_planted_optimum": err},
+            "parity_rank0": parity})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.stderr.write(f"bench c4: rank {rank}: members beyond the parity tolerance: {bad}\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

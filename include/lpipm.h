@@ -72,6 +72,7 @@ typedef struct {
     double   total_ms;     /* first kernel to last kernel of the solve                 */
     uint64_t adat_launches;
     uint64_t iterations;
+    uint64_t gemv_passes;  /* passes over A inside gemv_ms (a 2-vector pass reads A once and counts once) */
 } lpipm_phase_times;
 
 typedef struct lpipm_ctx lpipm_ctx; /* opaque: device buffers + stream for one (thread, device) */
@@ -173,6 +174,18 @@ int lpipm_upload_lockstep(lpipm_ctx* ctx, uint64_t count, uint64_t m, uint64_t n
                           const double* const* b, const double* const* c, const double* c0 /* nullable */);
 int lpipm_solve_lockstep(lpipm_ctx* ctx, const lpipm_opts* opts, double* const* x_slack_out, double* fun_out,
                          uint64_t* iterations_out, int32_t* status_out);
+/* The same with the solutions left in HBM: x / tau of LP i goes to the DEVICE row x_dev_out + i * row_stride doubles
+ * (row_stride >= n), device to device on the ctx's stream -- the packed block a sharded batch then all-gathers (RCCL)
+ * without a host round trip.  Rows of members without a solution (Infeasible, ...) are left untouched. */
+int lpipm_solve_lockstep_device(lpipm_ctx* ctx, const lpipm_opts* opts, void* x_dev_out, uint64_t row_stride,
+                                double* fun_out, uint64_t* iterations_out, int32_t* status_out);
+/* lpipm_solve_batch with device-resident results: member i's x / tau goes to x_dev_out + i * row_stride doubles
+ * (row_stride >= max n[i]); everything else as lpipm_solve_batch. */
+int lpipm_solve_batch_device(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const uint64_t* n,
+                             const double* const* A, const double* const* b, const double* const* c,
+                             const double* c0 /* nullable */, const lpipm_opts* opts, void* x_dev_out,
+                             uint64_t row_stride, double* fun_out /* nullable */, uint64_t* iterations_out /* nullable */,
+                             int32_t* status_out);
 /* lpipm_solve_batch groups members of equal shape into lockstep batches: max_group -1 = auto (default: chunks
  * of up to 32 within the memory budget, the upload of one chunk overlapping the solve of the previous one), 0 = never, > 0 = largest group. */
 int lpipm_set_batch_lockstep(lpipm_ctx* ctx, int max_group);

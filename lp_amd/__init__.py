@@ -313,6 +313,38 @@ class Context:
             out.append((int(st[i]), xs[i] if has_x else None, fun[i] if has_x else None, int(its[i])))
         return out
 
+    def solve_lockstep_device(self, opts: "_capi.Opts", x_dev_ptr: int, row_stride: int):
+        """Like solve_lockstep, the solutions left in HBM: x / tau of LP i goes to the device row
+        x_dev_ptr + i * row_stride doubles (lpipm_solve_lockstep_device).  -> list of (status, fun | None, iterations)"""
+        K = self._lock[0]
+        fun = (C.c_double * K)(); its = (C.c_uint64 * K)(); st = (C.c_int32 * K)()
+        rc = _capi.lib().lpipm_solve_lockstep_device(self._h, C.byref(opts), C.c_void_p(int(x_dev_ptr)), int(row_stride),
+                                                     fun, its, st)
+        if rc != _capi.OK:
+            _raise_for(rc)
+        return [(int(st[i]), fun[i] if st[i] in (_capi.OK, _capi.ITERATION_LIMIT) else None, int(its[i])) for i in range(K)]
+
+    def solve_batch_device(self, problems, opts: "_capi.Opts", x_dev_ptr: int, row_stride: int):
+        """lpipm_solve_batch_device over [(A, b, c, c0), ...]: member i's x / tau goes to the device row
+        x_dev_ptr + i * row_stride doubles.  -> list of (status, fun | None, iterations)"""
+        K = len(problems)
+        if K == 0:
+            return []
+        As = [_f64(p[0]) for p in problems]; bs = [_f64(p[1]) for p in problems]; cs = [_f64(p[2]) for p in problems]
+        for A, b, c in zip(As, bs, cs):
+            if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
+                raise IncompatibleInputDimensions()
+        dp = C.POINTER(C.c_double)
+        arr = lambda lst: (dp * K)(*[_p(a) for a in lst])
+        m = (C.c_uint64 * K)(*[A.shape[0] for A in As]); n = (C.c_uint64 * K)(*[A.shape[1] for A in As])
+        c0 = (C.c_double * K)(*[float(p[3]) if len(p) > 3 else 0.0 for p in problems])
+        fun = (C.c_double * K)(); its = (C.c_uint64 * K)(); st = (C.c_int32 * K)()
+        rc = _capi.lib().lpipm_solve_batch_device(self._h, K, m, n, arr(As), arr(bs), arr(cs), c0, C.byref(opts),
+                                                  C.c_void_p(int(x_dev_ptr)), int(row_stride), fun, its, st)
+        if rc != _capi.OK:
+            _raise_for(rc)
+        return [(int(st[i]), fun[i] if st[i] in (_capi.OK, _capi.ITERATION_LIMIT) else None, int(its[i])) for i in range(K)]
+
     def solve_batch(self, problems, opts: "_capi.Opts"):
         """lpipm_solve_batch over [(A, b, c, c0), ...] (any mix of shapes; equal shapes run as lockstep batches).
         -> list of (status, x_slack | None, fun | None, iterations)"""
@@ -342,7 +374,9 @@ class Context:
         """-> (status, x_slack | None, fun, iterations, log rows)"""
         x = None if x_dev_ptr is not None else np.full(self.n, np.nan)
         fun, it = C.c_double(np.nan), C.c_uint64(0)
-        nlog = int(min(opts.max_iter, 1 << 20)) if want_log else 0
+        if want_log and opts.max_iter > (1 << 20):      # the library writes one row per iteration, up to max_iter of them
+            raise InvalidParameter("want_log with max_iter > 2^20")
+        nlog = int(opts.max_iter) if want_log else 0
         log = (_capi.IterRow * max(nlog, 1))() if want_log else None
         if x_dev_ptr is not None:
             rc = _capi.lib().lpipm_solve_device(self._h, C.byref(opts), C.c_void_p(int(x_dev_ptr)), C.byref(fun),

@@ -26,7 +26,8 @@ class IterRow(C.Structure):  # lpipm_iter_row
 class PhaseTimes(C.Structure):  # lpipm_phase_times
     _fields_ = [("adat_ms", C.c_double), ("potrf_ms", C.c_double), ("trsv_ms", C.c_double),
                 ("gemv_ms", C.c_double), ("vec_ms", C.c_double), ("total_ms", C.c_double),
-                ("adat_launches", C.c_uint64), ("iterations", C.c_uint64)]
+                ("adat_launches", C.c_uint64), ("iterations", C.c_uint64),
+                ("gemv_passes", C.c_uint64)]
 
 
 # every symbol include/lpipm.h declares: name -> (restype, argtypes)
@@ -51,6 +52,9 @@ SYMBOLS = {
     "lpipm_upload_nsplit": (C.c_int, [_vp, _u64, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
     "lpipm_upload_lockstep": (C.c_int, [_vp, _u64, _u64, _u64, _dpp, _dpp, _dpp, _dp]),
     "lpipm_solve_lockstep": (C.c_int, [_vp, C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
+    "lpipm_solve_lockstep_device": (C.c_int, [_vp, C.POINTER(Opts), _vp, _u64, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
+    "lpipm_solve_batch_device": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,
+                                           C.POINTER(Opts), _vp, _u64, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
     "lpipm_set_batch_lockstep": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_batch_concurrency": (C.c_int, [_vp, C.c_int]),
     "lpipm_set_profiling": (C.c_int, [_vp, C.c_int]),

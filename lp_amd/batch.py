@@ -3,9 +3,11 @@
 LPs are independent, so the path shards with NO data-path collective: rank r solves the contiguous
 block `shard_range(count, world, r)` on its own GPU (its own lpipm_ctx / stream), and the batch ends
 with exactly ONE collective -- an all-gather (RCCL over xGMI when the backend is "nccl") of a packed
-[shard_max, n_max + 3] block per rank holding x / tau, fun, iterations and status of each LP.
-On the GPU the shard goes to lpipm_solve_batch in one call: LPs of equal shape advance as lockstep
-batches (one kernel launch covers all of them), odd shapes one at a time.
+[shard_max, n_max + 3] DEVICE block per rank holding x / tau, fun, iterations and status of each LP.
+On the GPU the shard goes to lpipm_solve_batch_device in one call: LPs of equal shape advance as lockstep
+batches (one kernel launch covers all of them), odd shapes one at a time, and every member's x / tau is
+copied device to device into its row of the packed block -- no solution vector visits the host before the
+gather (only the 3 scalars per LP do).
 One process per GPU, `torch.distributed` for the plumbing; nothing here computes on the CPU.
 `solve_fn` exists so that the sharding / packing / gather logic can be unit-tested on CPU ranks
 (gloo) with an injected solver; the default is the HIP path and it fails loudly without a GPU.
@@ -39,25 +41,33 @@ def solve_batch_sharded(problems, opts=None, ctx=None, group=None, device=None, 
     mine = shard_range(count, world, rank)
     shard_max = -(-count // world) if count else 0
     n_max = max((np.asarray(p[2]).shape[0] for p in problems), default=0)
-    shard_results = None
+    rows = max(shard_max, 1)
+    meta = np.zeros((rows, 3))
+    meta[:, 2] = -1.0                                 # status -1: padding slot, no LP here
     if solve_fn is None:                              # the product path: the whole shard in one library call
         import lp_amd
         ctx = ctx or lp_amd.default_context(device.index if device is not None and device.index is not None else 0)
         opts = opts or lp_amd.InteriorPoint.default().opts()
-        shard_results = ctx.solve_batch([problems[i] for i in mine], opts)
         device = device or torch.device("cuda", ctx.device)
-    device = device or torch.device("cpu")
-    host = np.zeros((max(shard_max, 1), n_max + 3))
-    host[:, n_max + 2] = -1.0                         # status -1: padding slot, no LP here
-    for slot, i in enumerate(mine):
-        A, b, c, c0 = problems[i]
-        n = np.asarray(c).shape[0]
-        rc, x, fun, it = shard_results[slot] if shard_results is not None else solve_fn(A, b, c, c0, None)
-        if x is not None:
-            host[slot, :n] = np.asarray(x, dtype=np.float64)
-        ok = rc in (_capi.OK, _capi.ITERATION_LIMIT)
-        host[slot, n_max:] = (fun if ok and fun is not None else float("nan"), float(it), float(rc))
-    packed = torch.from_numpy(host).to(device)        # one H2D of the shard's packed block
+        packed = torch.zeros((rows, n_max + 3), dtype=torch.float64, device=device)
+        torch.cuda.synchronize(device)                # the zero fill runs on torch's stream, the solver on its own
+        res = ctx.solve_batch_device([problems[i] for i in mine], opts, packed.data_ptr(), n_max + 3)
+        for slot, (rc, fun, it) in enumerate(res):
+            meta[slot] = (fun if fun is not None else float("nan"), float(it), float(rc))
+        packed[:, n_max:] = torch.from_numpy(meta).to(device)       # 3 scalars per LP; x rows never left the device
+    else:                                             # CPU-rank tests: injected solver, host rows
+        device = device or torch.device("cpu")
+        host = np.zeros((rows, n_max + 3))
+        for slot, i in enumerate(mine):
+            A, b, c, c0 = problems[i]
+            n = np.asarray(c).shape[0]
+            rc, x, fun, it = solve_fn(A, b, c, c0, None)
+            if x is not None:
+                host[slot, :n] = np.asarray(x, dtype=np.float64)
+            ok = rc in (_capi.OK, _capi.ITERATION_LIMIT)
+            meta[slot] = (fun if ok and fun is not None else float("nan"), float(it), float(rc))
+        host[:, n_max:] = meta
+        packed = torch.from_numpy(host).to(device)
     if world > 1:
         flat = torch.empty((world * packed.shape[0], packed.shape[1]), dtype=torch.float64, device=device)
         dist.all_gather_into_tensor(flat, packed, group=group)         # the single collective of the batch

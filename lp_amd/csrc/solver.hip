@@ -74,6 +74,7 @@ struct lpipm_ctx {
     size_t nmarks = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     double tag_ms[T_NTAGS] = {0, 0, 0, 0, 0};
+    uint64_t gemv_passes = 0;
     lpipm_phase_times times{};
     // batch mode: extra contexts (own stream + buffers) driven by host threads, see lpipm_solve_batch
     std::vector<lpipm_ctx*> workers;
@@ -286,11 +287,14 @@ static std::vector<int2> adat_tile_order(int nt) {
 // Output tile edge of the inverse-merge GEMMs: 64 (a stage of one LP is a few dozen latency-bound tiles: factorisation
 // 422 -> 358 us at m = 512, 719 -> 547 at 1024, 2556 -> 2398 at 4096; a batch that fills the chip is indifferent).
 // LPIPM_MERGE_EDGE=128 restores the 128x128 tiles (measurement knob, scripts/potrf_sizes.py).
-// Width of the diagonal super-blocks whose explicit inverses feed the triangular solves.  LPIPM_SUPER=<multiple of 128>
-// overrides it (measurement knob: accuracy / speed A-B of the solve path).
-static int super_for(int B) {
+// Width of the diagonal super-blocks whose explicit inverses feed the triangular solves: a function of the problem
+// size alone, so that an LP goes through exactly the same arithmetic alone and as a member of a lockstep batch (the
+// two paths are bit-identical, tests/test_gpu_c4_members.py).  512 up to m = 2048: the last doubling level of the
+// inverse (1024) costs a flop-bound batch more than the two solve steps it saves, and a single small LP about as much
+// as it gains.  LPIPM_SUPER=<multiple of 128> overrides it (measurement knob).
+static int super_for(int mp) {
     if (const char* e = getenv("LPIPM_SUPER")) { const int w = atoi(e); if (w >= NB && w % NB == 0 && w <= 4096) return w; }
-    return B >= 8 ? 512 : SUPER;
+    return mp <= 2048 ? 512 : SUPER;
 }
 static int merge_edge_for(int) {
     if (const char* e = getenv("LPIPM_MERGE_EDGE")) return atoi(e) == 128 ? 128 : 64;
@@ -318,9 +322,7 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.status = ar.take<StatusRec>(1);
     v.potrf_info = ar.take<int32_t>(1); v.flags = ar.take<int>(1); v.done = ar.take<int>(1);
     c->M = ar.take<double>(mp * mp);
-    // a batch that fills the chip is flop-bound: the last doubling level of the inverse (1024) costs more than the
-    // two extra solve steps it saves
-    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->B), merge_edge_for(c->B)));
+    LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->mp), merge_edge_for(c->B)));
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
@@ -477,11 +479,13 @@ extern "C" int lpipm_upload_ub_eq(lpipm_ctx* c, uint64_t n, uint64_t m_ub, const
 // identity block of the slack columns
 static hipError_t ctx_gemv_n(lpipm_ctx* c, int nrhs, const double* W, const double* add0, const double* add1, double* Y,
                              const Batch& bt) {
+    ++c->gemv_passes;
     hipError_t e = launch_gemv_n(c->A, c->npa, (int)c->m, c->npa, nrhs, W, c->np, add0, add1, Y, c->mp, c->st, 1.0, bt);
     if (e != hipSuccess) return e;
     return launch_slack_n(c->ns, c->nx, nrhs, W, c->np, Y, c->mp, c->st, bt);
 }
 static hipError_t ctx_gemv_t(lpipm_ctx* c, int nrhs, const double* V, const Batch& bt) {
+    ++c->gemv_passes;
     hipError_t e = launch_gemv_t(c->A, c->npa, c->mp, c->npa, nrhs, V, c->mp, c->ATpart, c->st, c->np, bt);
     if (e != hipSuccess) return e;
     return launch_slack_t(c->ns, c->nx, nrhs, c->nsplit, V, c->mp, c->ATpart, c->np, c->st, bt);
@@ -655,6 +659,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
     c->times = lpipm_phase_times{};
     c->nmarks = 0;
+    c->gemv_passes = 0;
     uint64_t adat_launches = 0;
     if (c->profiling) LP_HIP(hipEventRecord(c->ev_begin, st));
 
@@ -730,6 +735,8 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         c->times.trsv_ms = c->tag_ms[T_TRSV]; c->times.gemv_ms = c->tag_ms[T_GEMV];
         c->times.vec_ms = c->tag_ms[T_VEC];
         c->times.adat_launches = adat_launches; c->times.iterations = iteration;
+        // the speculatively enqueued head of the iteration after the last holds no GEMV pass: every counted pass ran
+        c->times.gemv_passes = c->gemv_passes;
     }
     return ret;
 }
@@ -751,9 +758,16 @@ extern "C" int lpipm_solve_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev
 // k_scalar_indicators sets an LP's `done` word on the conditions that end the reference's loop
 // (mod.rs:215, :231-233) and every later kernel skips it, so its iterate stays what it was; the host
 // mirrors the same decisions from the status records to count iterations and pick the return codes.
-static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_out, double* fun_out,
+// Where the solutions of a batch go: per-member host pointers, or rows of one device buffer.
+struct XOut {
+    double* const* host = nullptr;
+    char* dev = nullptr;
+    size_t stride_bytes = 0;
+    bool valid() const { return host || dev; }
+};
+static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, const uint64_t* rows, double* fun_out,
                           uint64_t* its_out, int32_t* status_out) {
-    if (!c || !o || !x_out || !status_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c || !o || !xo.valid() || !status_out) return LPIPM_ERR_BAD_ARGUMENT;
     if (!(o->alpha0 > 0.0) || !(o->alpha0 < 1.0)) return LPIPM_INVALID_PARAMETER;   // mod.rs:118-128
     if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
     if (o->solver_type != LPIPM_SOLVER_CHOLESKY) return LPIPM_ERR_UNSUPPORTED;      // the QR arms are single-LP
@@ -791,10 +805,13 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_ou
         if (ret[i] < 0) { ret[i] = LPIPM_ITERATION_LIMIT; its[i] = o->max_iter; }   // mod.rs:237-239
     LP_TRY(vec_final_x(v, c->xout, st, nullptr));                            // mod.rs:231/238, :165 (every LP)
     LP_TRY(copy_status(c));
-    for (int i = 0; i < B; ++i)
-        if ((ret[i] == LPIPM_OK || ret[i] == LPIPM_ITERATION_LIMIT) && x_out[i])
-            LP_HIP(hipMemcpyAsync(x_out[i], (const char*)c->xout + (size_t)i * c->bstride, c->n * sizeof(double),
-                                  hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < B; ++i) {     // rows[i]: member i's row in the caller's numbering (identity when null)
+        if (ret[i] != LPIPM_OK && ret[i] != LPIPM_ITERATION_LIMIT) continue;
+        const uint64_t row = rows ? rows[i] : (uint64_t)i;
+        const char* src = (const char*)c->xout + (size_t)i * c->bstride;
+        if (xo.dev) LP_HIP(hipMemcpyAsync(xo.dev + row * xo.stride_bytes, src, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        else if (xo.host[row]) LP_HIP(hipMemcpyAsync(xo.host[row], src, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     LP_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < B; ++i) {
         status_out[i] = ret[i];
@@ -812,7 +829,14 @@ extern "C" int lpipm_upload_lockstep(lpipm_ctx* c, uint64_t count, uint64_t m, u
 }
 extern "C" int lpipm_solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* const* x_slack_out, double* fun_out,
                                     uint64_t* iterations_out, int32_t* status_out) {
-    return solve_lockstep(c, o, x_slack_out, fun_out, iterations_out, status_out);
+    XOut xo; xo.host = x_slack_out;
+    return solve_lockstep(c, o, xo, nullptr, fun_out, iterations_out, status_out);
+}
+extern "C" int lpipm_solve_lockstep_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev_out, uint64_t row_stride,
+                                           double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
+    if (!c || !x_dev_out || row_stride < c->n) return LPIPM_ERR_BAD_ARGUMENT;
+    XOut xo; xo.dev = (char*)x_dev_out; xo.stride_bytes = row_stride * sizeof(double);
+    return solve_lockstep(c, o, xo, nullptr, fun_out, iterations_out, status_out);
 }
 
 // A shard of independent LPs on one device.
@@ -823,11 +847,11 @@ extern "C" int lpipm_solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, double* c
 //     each driven by its own host thread -- solve different members at the same time; independent
 //     streams need no cross-stream synchronisation.  Members are handed out through an atomic counter.
 // Every member's result depends only on its own inputs.
-extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
-                                 const double* const* A, const double* const* b, const double* const* cc,
-                                 const double* c0, const lpipm_opts* o, double* const* x_slack_out,
-                                 double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
-    if (!c || !o || (count && (!m || !n || !A || !b || !cc || !x_slack_out || !status_out)))
+static int batch_impl(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
+                      const double* const* A, const double* const* b, const double* const* cc,
+                      const double* c0, const lpipm_opts* o, const XOut& xo,
+                      double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
+    if (!c || !o || (count && (!m || !n || !A || !b || !cc || !xo.valid() || !status_out)))
         return LPIPM_ERR_BAD_ARGUMENT;
     std::vector<uint64_t> rest;                      // members left to the one-by-one path
     if (c->lockstep_max != 0 && o->solver_type == LPIPM_SOLVER_CHOLESKY) {
@@ -896,12 +920,11 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
                 if (q + 1 < chunks.size()) up = std::thread([&, q] { rc_next = upload_chunk(pipe[(q + 1) & 1], chunks[q + 1]); });
                 const size_t g = ch.g;
                 std::vector<double> gfun(g, NAN);
-                std::vector<double*> gx(g);
-                std::vector<uint64_t> gits(g, 0);
+                std::vector<uint64_t> gits(g, 0), grow(g);
                 std::vector<int32_t> gst(g, 0);
-                for (size_t k = 0; k < g; ++k) gx[k] = x_slack_out[grp[ch.k0 + k]];
+                for (size_t k = 0; k < g; ++k) grow[k] = grp[ch.k0 + k];
                 int rc = rc_up;
-                if (rc == LPIPM_OK) rc = solve_lockstep(w, o, gx.data(), gfun.data(), gits.data(), gst.data());
+                if (rc == LPIPM_OK) rc = solve_lockstep(w, o, xo, grow.data(), gfun.data(), gits.data(), gst.data());
                 if (up.joinable()) up.join();
                 if (rc >= 100) return rc;            // runtime failure: nothing sensible to continue with
                 for (size_t k = 0; k < g; ++k) {
@@ -947,7 +970,9 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
             int rc = lpipm_upload(w, m[i], n[i], A[i], n[i], b[i], cc[i], c0 ? c0[i] : 0.0);
             double fun = NAN;
             uint64_t it = 0;
-            if (rc == LPIPM_OK) rc = lpipm_solve(w, &opts, x_slack_out[i], &fun, &it, nullptr);
+            if (rc == LPIPM_OK)
+                rc = xo.dev ? solve_impl(w, &opts, nullptr, xo.dev + i * xo.stride_bytes, &fun, &it, nullptr)
+                            : lpipm_solve(w, &opts, xo.host[i], &fun, &it, nullptr);
             status_out[i] = rc;
             if (fun_out) fun_out[i] = fun;
             if (iterations_out) iterations_out[i] = it;
@@ -959,6 +984,24 @@ extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m
     run(c);
     for (std::thread& t : threads) t.join();
     return fatal.load();
+}
+
+extern "C" int lpipm_solve_batch(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
+                                 const double* const* A, const double* const* b, const double* const* cc,
+                                 const double* c0, const lpipm_opts* o, double* const* x_slack_out,
+                                 double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
+    XOut xo; xo.host = x_slack_out;
+    return batch_impl(c, count, m, n, A, b, cc, c0, o, xo, fun_out, iterations_out, status_out);
+}
+extern "C" int lpipm_solve_batch_device(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uint64_t* n,
+                                        const double* const* A, const double* const* b, const double* const* cc,
+                                        const double* c0, const lpipm_opts* o, void* x_dev_out, uint64_t row_stride,
+                                        double* fun_out, uint64_t* iterations_out, int32_t* status_out) {
+    if (count && !x_dev_out) return LPIPM_ERR_BAD_ARGUMENT;
+    for (uint64_t i = 0; i < count && n; ++i)
+        if (n[i] > row_stride) return LPIPM_ERR_BAD_ARGUMENT;
+    XOut xo; xo.dev = (char*)x_dev_out; xo.stride_bytes = row_stride * sizeof(double);
+    return batch_impl(c, count, m, n, A, b, cc, c0, o, xo, fun_out, iterations_out, status_out);
 }
 
 extern "C" int lpipm_set_batch_lockstep(lpipm_ctx* c, int max_group) {
@@ -1053,12 +1096,12 @@ static int kbuf_ensure(lpipm_ctx* c, int mp) {
     LP_TRY(dalloc(c->kallocs, nullptr, &c->kinfo, 1, c->st));
     LP_TRY(dalloc(c->kallocs, nullptr, &c->ktau, (size_t)mp, c->st));
     Arena measure;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st, super_for(1), merge_edge_for(1)));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, measure, false, c->st, super_for(mp), merge_edge_for(1)));
     char* kar = nullptr;
     LP_TRY(dalloc(c->kallocs, nullptr, &kar, measure.off + 256, c->st));   // zeroed
     Arena real;
     real.base = kar;
-    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st, super_for(1), merge_edge_for(1)));
+    LP_HIP(factor_plan_create(c->kplan, c->kM, mp, mp, real, true, c->st, super_for(mp), merge_edge_for(1)));
     c->kmp = mp;
     return LPIPM_OK;
 }

@@ -243,8 +243,9 @@ def test_solve_batch_shard(built):
 
 
 def test_sharded_batch_device_path(built):
-    """lp_amd.batch on the real HIP solver (world = 1: the shard is the whole batch; x / tau is written by
-    the library straight into the packed device rows): C4-shaped members + ragged + infeasible."""
+    """lp_amd.batch on the real HIP solver (world = 1: the shard is the whole batch; x / tau is copied device to
+    device by lpipm_solve_batch_device into the rows of the packed block that is then gathered): C4-shaped members
+    (a lockstep group) + ragged + infeasible (one-by-one path)."""
     import lp_amd as lp
     from lp_amd import synth
     from lp_amd.batch import solve_batch_sharded
