@@ -217,6 +217,9 @@ int lpipm_k_potrf(lpipm_ctx* ctx, uint64_t m, double* M_inout, int32_t* info_out
  * L = the factor of a preceding lpipm_k_potrf on this ctx (kept on device).  R, V: nrhs x m. */
 int lpipm_k_chol_solve(lpipm_ctx* ctx, uint64_t m, int nrhs, const double* R, double* V,
                        int repeats, double* ms_out);
+/* The residual of the refinement step of the Cholesky solve (solver.hip chol_solve_refined): Rho[q] = R0[q] - M.V[q],
+ * q < nrhs (1|2), for a symmetric m x m row-major M of which only the LOWER triangle is read.  V, R0, Rho: nrhs x m. */
+int lpipm_k_symv_residual(lpipm_ctx* ctx, uint64_t m, const double* M, int nrhs, const double* V, const double* R0, double* Rho);
 /* newton_equations.rs:133-149, :155-166 (the Inverse / LeastSquares arms): V[r] = R^-1 Q^T R[r] with
  * M = QR a Householder factorisation of the symmetric m x m matrix M (row-major; only the lower
  * triangle is read), nrhs 1|2, m <= 16384.  info_out: 0, or k+1 for a zero column / zero R[k][k].

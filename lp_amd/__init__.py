@@ -420,6 +420,12 @@ class Context:
         _raise_for(_capi.lib().lpipm_k_chol_solve(self._h, m, R.shape[0], _p(R), _p(V), repeats, C.byref(ms)))
         return V, ms.value
 
+    def k_symv_residual(self, M, V, R0):
+        M = _f64(M); V = np.atleast_2d(_f64(V)); R0 = np.atleast_2d(_f64(R0))
+        Rho = np.empty_like(V)
+        _raise_for(_capi.lib().lpipm_k_symv_residual(self._h, M.shape[0], _p(M), V.shape[0], _p(V), _p(R0), _p(Rho)))
+        return Rho
+
     def k_qr_solve(self, M, R):
         M = _f64(M)
         R = np.atleast_2d(_f64(R))

@@ -62,6 +62,7 @@ SYMBOLS = {
     "lpipm_k_adat": (C.c_int, [_vp, _dp, _dp, C.c_int, _dp]),
     "lpipm_k_potrf": (C.c_int, [_vp, _u64, _dp, C.POINTER(C.c_int32), C.c_int, _dp]),
     "lpipm_k_chol_solve": (C.c_int, [_vp, _u64, C.c_int, _dp, _dp, C.c_int, _dp]),
+    "lpipm_k_symv_residual": (C.c_int, [_vp, _u64, _dp, C.c_int, _dp, _dp, _dp]),
     "lpipm_k_qr_solve": (C.c_int, [_vp, _u64, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_int32), _dp]),
     "lpipm_k_gemv_n": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
     "lpipm_k_gemv_t": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),

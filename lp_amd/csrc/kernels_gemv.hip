@@ -114,6 +114,164 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// rho = r0 - M.v for a symmetric M of which only the LOWER triangle is stored (the image A.D.A^T leaves), ONE read
+// of that triangle: a stored element M(r,c), c < r, serves row r (M(r,c).v_c) and, as M(c,r), row c (M(r,c).v_r).
+// This is the residual of the iterative-refinement step that makes the Cholesky solve of the normal equations as
+// accurate as the reference's substitution (newton_equations.rs:151-169; the factor is consumed through explicit
+// inverses of its diagonal super-blocks here, which alone loses digits on the ill-conditioned M of the last
+// iterations: DESIGN.md 3.3).
+//   unit (bi, ch): rows [64 bi, 64 bi + 64) x columns [512 ch, 512 ch + 512) of the lower triangle; wave w takes rows
+//   w, w+4, ...; a lane holds 2 adjacent columns per 128-column step:
+//     row part     slabA[ch][q][r]  = sum_{c in chunk, c <= r} M(r,c) v_q[c]            (wave reduction per row)
+//     column part  slabB[bi][q][c]  = sum_{r in block, r > c} M(r,c) v_q[r]             (lane accumulators, 4 waves added)
+//   symv_fold: rho_q[i] = r0_q[i] - ( sum_ch slabA[ch][q][i] + sum_{bi >= i/64} slabB[bi][q][i] ), fixed order.
+// The products are accumulated in DOUBLED precision (error-free product by fma, error-free sum; Ogita-Rump-Oishi
+// "Dot2"): a residual taken in working precision carries a rounding error of the size of the backward error of a
+// stable solve, so refining with it makes good solves worse (measured: C4 member 217, rho_mu after the last
+// iteration 1.3e-9 unrefined / 3.0e-8 refined with a plain residual, super-block width 128).  The kernel is bound by
+// the one read of the triangle; the extra flops are free.
+constexpr int SY_ROWS = 64, SY_COLS = 512;
+struct dd { double hi, lo; };
+// (contraction off: `hi + a*b` fused into one fma would not be the sum the error terms below are taken of)
+__device__ __forceinline__ void dd_add_prod(dd& s, double a, double b) {       // s += a*b, a*b taken exactly
+#pragma clang fp contract(off)
+    const double p = a * b, e = fma(a, b, -p);
+    const double t = s.hi + p, bb = t - s.hi;
+    s.lo += ((s.hi - (t - bb)) + (p - bb)) + e;
+    s.hi = t;
+}
+__device__ __forceinline__ void dd_add(dd& s, double hi, double lo) {           // s += (hi + lo)
+#pragma clang fp contract(off)
+    const double t = s.hi + hi, bb = t - s.hi;
+    s.lo += ((s.hi - (t - bb)) + (hi - bb)) + lo;
+    s.hi = t;
+}
+__host__ __device__ inline int symv_units(int mp) { const int nb = mp / SY_ROWS; int u = 0; for (int bi = 0; bi < nb; ++bi) u += bi / 8 + 1; return u; }
+// slabs: [index][q][hi|lo][mp]
+template <int NRHS>
+__global__ __launch_bounds__(256) void symv_lower_kernel(const double* __restrict__ M, long long ld, int mp,
+                                                         const double* __restrict__ V, long long ldv,
+                                                         double* __restrict__ slabA, double* __restrict__ slabB, BatchK bk) {
+    if (batch_done(bk)) return;
+    M = batch_ptr(M, bk); V = batch_ptr(V, bk); slabA = batch_ptr(slabA, bk); slabB = batch_ptr(slabB, bk);
+    // unit -> (bi, ch): row blocks 8g .. 8g+7 have g+1 column chunks each
+    int u = blockIdx.x, g = 0;
+    while (4 * (g + 1) * (g + 2) <= u) ++g;
+    u -= 4 * g * (g + 1);
+    const int bi = 8 * g + u / (g + 1), ch = u % (g + 1);
+    const int r0 = bi * SY_ROWS, c0 = ch * SY_COLS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double vrow[NRHS][SY_ROWS];
+    __shared__ double csum[4][NRHS][2][SY_COLS];
+    for (int e = threadIdx.x; e < NRHS * SY_ROWS; e += 256) vrow[e / SY_ROWS][e % SY_ROWS] = V[(long long)(e / SY_ROWS) * ldv + r0 + e % SY_ROWS];
+    d2 vc[SY_COLS / 128][NRHS];
+    dd cacc[SY_COLS / 128][NRHS][2];
+#pragma unroll
+    for (int s = 0; s < SY_COLS / 128; ++s)
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) {
+            const int col = c0 + s * 128 + 2 * lane;
+            vc[s][q] = col < mp ? *(const d2*)(V + (long long)q * ldv + col) : (d2){0.0, 0.0};
+            cacc[s][q][0] = dd{0.0, 0.0}; cacc[s][q][1] = dd{0.0, 0.0};
+        }
+    __syncthreads();
+    for (int rr = wave; rr < SY_ROWS; rr += 4) {
+        const int r = r0 + rr;
+        const double* row = M + (long long)r * ld + c0 + 2 * lane;
+        dd racc[NRHS];
+        double vr[NRHS];
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q) { racc[q] = dd{0.0, 0.0}; vr[q] = vrow[q][rr]; }
+#pragma unroll
+        for (int s = 0; s < SY_COLS / 128; ++s) {
+            const int col = c0 + s * 128 + 2 * lane;
+            if (c0 + s * 128 > r) break;                        // wave-uniform: nothing of the lower triangle further right
+            d2 a = (d2){0.0, 0.0};
+            if (col <= r) a = *(const d2*)(row + s * 128);
+            if (col + 1 > r) a[1] = 0.0;                        // above the diagonal: not part of the stored triangle
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) {
+                dd_add_prod(racc[q], a[0], vc[s][q][0]);
+                dd_add_prod(racc[q], a[1], vc[s][q][1]);
+                // the diagonal element belongs to the row part only
+                dd_add_prod(cacc[s][q][0], col == r ? 0.0 : a[0], vr[q]);
+                dd_add_prod(cacc[s][q][1], col + 1 == r ? 0.0 : a[1], vr[q]);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) {
+                const double h = __shfl_xor(racc[q].hi, off, 64), l = __shfl_xor(racc[q].lo, off, 64);
+                dd_add(racc[q], h, l);
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NRHS; ++q) {
+                slabA[(((long long)ch * NRHS + q) * 2 + 0) * mp + r] = racc[q].hi;
+                slabA[(((long long)ch * NRHS + q) * 2 + 1) * mp + r] = racc[q].lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SY_COLS / 128; ++s)
+#pragma unroll
+        for (int q = 0; q < NRHS; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                csum[wave][q][0][s * 128 + 2 * lane + h] = cacc[s][q][h].hi;
+                csum[wave][q][1][s * 128 + 2 * lane + h] = cacc[s][q][h].lo;
+            }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NRHS * SY_COLS; e += 256) {
+        const int q = e / SY_COLS, c = e % SY_COLS;
+        if (c0 + c >= mp) continue;
+        dd t{csum[0][q][0][c], csum[0][q][1][c]};
+#pragma unroll
+        for (int w = 1; w < 4; ++w) dd_add(t, csum[w][q][0][c], csum[w][q][1][c]);
+        slabB[(((long long)bi * NRHS + q) * 2 + 0) * mp + c0 + c] = t.hi;
+        slabB[(((long long)bi * NRHS + q) * 2 + 1) * mp + c0 + c] = t.lo;
+    }
+}
+template <int NRHS>
+__global__ __launch_bounds__(256) void symv_fold_kernel(const double* __restrict__ R0, long long ldr, int mp,
+                                                        const double* __restrict__ slabA, const double* __restrict__ slabB,
+                                                        double* __restrict__ Rho, long long ldo, BatchK bk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= mp || batch_done(bk)) return;
+    R0 = batch_ptr(R0, bk); slabA = batch_ptr(slabA, bk); slabB = batch_ptr(slabB, bk); Rho = batch_ptr(Rho, bk);
+    const int nb = mp / SY_ROWS, bi0 = i / SY_ROWS, nch = (bi0 * SY_ROWS + SY_ROWS + SY_COLS - 1) / SY_COLS;
+#pragma unroll
+    for (int q = 0; q < NRHS; ++q) {
+        dd t{0.0, 0.0};
+        for (int ch = 0; ch < nch; ++ch)
+            dd_add(t, slabA[(((long long)ch * NRHS + q) * 2 + 0) * mp + i], slabA[(((long long)ch * NRHS + q) * 2 + 1) * mp + i]);
+        // column parts: every row block at or below row i (its 512-column chunk grid reaches column i)
+        for (int bi = bi0; bi < nb; ++bi)
+            dd_add(t, slabB[(((long long)bi * NRHS + q) * 2 + 0) * mp + i], slabB[(((long long)bi * NRHS + q) * 2 + 1) * mp + i]);
+        dd r{R0[(long long)q * ldr + i], 0.0};
+        dd_add(r, -t.hi, -t.lo);
+        Rho[(long long)q * ldo + i] = r.hi + r.lo;
+    }
+}
+// slab space (doubles) for an mp x mp symmetric product with up to 2 vectors (hi and lo parts)
+size_t symv_slab_doubles(int mp) { return (size_t)((mp + SY_COLS - 1) / SY_COLS + mp / SY_ROWS) * 4 * mp; }
+hipError_t launch_symv_residual(const double* M, int64_t ld, int mp, int nrhs, const double* V, int64_t ldv, const double* R0,
+                                int64_t ldr, double* Rho, int64_t ldo, double* slabs, hipStream_t st, const Batch& bt) {
+    double* slabA = slabs;
+    double* slabB = slabs + (size_t)((mp + SY_COLS - 1) / SY_COLS) * 4 * mp;
+    const dim3 grid(symv_units(mp), 1, bt.count), fgrid((mp + 255) / 256, 1, bt.count);
+    if (nrhs == 1) {
+        hipLaunchKernelGGL(symv_lower_kernel<1>, grid, dim3(256), 0, st, M, (long long)ld, mp, V, (long long)ldv, slabA, slabB, batch_k(bt));
+        hipLaunchKernelGGL(symv_fold_kernel<1>, fgrid, dim3(256), 0, st, R0, (long long)ldr, mp, slabA, slabB, Rho, (long long)ldo, batch_k(bt));
+    } else {
+        hipLaunchKernelGGL(symv_lower_kernel<2>, grid, dim3(256), 0, st, M, (long long)ld, mp, V, (long long)ldv, slabA, slabB, batch_k(bt));
+        hipLaunchKernelGGL(symv_fold_kernel<2>, fgrid, dim3(256), 0, st, R0, (long long)ldr, mp, slabA, slabB, Rho, (long long)ldo, batch_k(bt));
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemv_n(const double* A, int64_t lda, int m, int np, int nrhs, const double* W,
                          int64_t ldw, const double* add0, const double* add1, double* Y, int64_t ldy,
                          hipStream_t st, double alpha, const Batch& bt) {

@@ -470,6 +470,37 @@ int vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr)
 void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_lower, dim3(mp), dim3(256), 0, st, M, ld, packed, dir);
 }
+// batch-aware helpers of the refined Cholesky solve: dst[q][i] (op)= src[q][i], q < nrhs, i < mp; and the copy of the
+// lower block-triangle of the normal-equations matrix that the refinement's residual is taken against
+__global__ __launch_bounds__(256) void k_rows_op(int mp, int nrhs, double* __restrict__ dst, const double* __restrict__ src, int add,
+                                                 BatchK bk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= mp || batch_done(bk)) return;
+    dst = batch_ptr(dst, bk); src = batch_ptr(src, bk);
+    for (int q = 0; q < nrhs; ++q) {
+        const long long e = (long long)q * mp + i;
+        dst[e] = add ? dst[e] + src[e] : src[e];
+    }
+}
+void vec_rows_copy(int mp, int nrhs, double* dst, const double* src, hipStream_t st, const Batch& bt) {
+    hipLaunchKernelGGL(k_rows_op, dim3((mp + 255) / 256, 1, bt.count), dim3(256), 0, st, mp, nrhs, dst, src, 0, batch_k(bt));
+}
+void vec_rows_add(int mp, int nrhs, double* dst, const double* src, hipStream_t st, const Batch& bt) {
+    hipLaunchKernelGGL(k_rows_op, dim3((mp + 255) / 256, 1, bt.count), dim3(256), 0, st, mp, nrhs, dst, src, 1, batch_k(bt));
+}
+// grid (row, 128-column block): block-row bi keeps column blocks 0..bi
+__global__ __launch_bounds__(64) void k_copy_lower(const double* __restrict__ M, double* __restrict__ M0, long long ld, BatchK bk) {
+    if (batch_done(bk)) return;
+    const int row = blockIdx.x, cb = blockIdx.y;
+    if (cb > (row >> 7)) return;
+    M = batch_ptr(M, bk); M0 = batch_ptr(M0, bk);
+    const long long e = (long long)row * ld + cb * 128 + 2 * threadIdx.x;
+    *(double2*)(M0 + e) = *(const double2*)(M + e);
+}
+void vec_copy_lower(const double* M, double* M0, long long ld, int mp, hipStream_t st, const Batch& bt) {
+    hipLaunchKernelGGL(k_copy_lower, dim3(mp, mp / 128, bt.count), dim3(64), 0, st, M, M0, ld, batch_k(bt));
+}
+
 void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st) {
     hipLaunchKernelGGL(k_add_rows, dim3((m + 255) / 256), dim3(256), 0, st, m, nrhs, Y, ldy, add0, add1);
 }

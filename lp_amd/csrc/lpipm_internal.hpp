@@ -185,6 +185,11 @@ constexpr int GEMVT_ROWS = 128;
 // np: columns processed (multiple of 2); slab: stride between slabs (0 = np)
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
                          int64_t ldv, double* Upart, hipStream_t st, int64_t slab = 0, const Batch& bt = Batch{});
+// Rho[q] = R0[q] - M.V[q] (q < nrhs) for a symmetric mp x mp M whose LOWER triangle is stored (one read of it);
+// slabs: symv_slab_doubles(mp) doubles of scratch.  The residual of the refinement step of the Cholesky solve.
+size_t symv_slab_doubles(int mp);
+hipError_t launch_symv_residual(const double* M, int64_t ld, int mp, int nrhs, const double* V, int64_t ldv, const double* R0,
+                                int64_t ldr, double* Rho, int64_t ldo, double* slabs, hipStream_t st, const Batch& bt = Batch{});
 // slack structure [I; 0] of the last ns columns (never stored), see kernels_gemv.hip
 hipError_t launch_slack_n(int ns, int nx, int nrhs, const double* W, int64_t ldw, double* Y, int64_t ldy, hipStream_t st,
                           const Batch& bt = Batch{});

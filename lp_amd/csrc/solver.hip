@@ -56,6 +56,8 @@ struct lpipm_ctx {
     FactorPlan plan, kplan;
     double *tau = nullptr, *ktau = nullptr;   // Householder scalars of the QR arms
     double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
+    double *M0 = nullptr, *R0 = nullptr, *Rho = nullptr, *symv_ws = nullptr;   // refinement of the Cholesky solve
+    int refine = -1;             // -1: decide from the environment at first use (LPIPM_REFINE=0 switches it off)
     int2* tile_list = nullptr;
     unsigned int* sk_claim = nullptr;   // claim word of the dynamic stream-K chunks of A.D.A^T
     int ntiles = 0, adat_nwg = 1;
@@ -323,6 +325,9 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.potrf_info = ar.take<int32_t>(1); v.flags = ar.take<int>(1); v.done = ar.take<int>(1);
     c->M = ar.take<double>(mp * mp);
     LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->mp), merge_edge_for(c->B)));
+    c->M0 = ar.take<double>(mp * mp);
+    c->R0 = ar.take<double>(2 * mp); c->Rho = ar.take<double>(2 * mp);
+    c->symv_ws = ar.take<double>(symv_slab_doubles(c->mp));
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
@@ -503,6 +508,26 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
 }
 
+// v = M^-1 r through the Cholesky factor (newton_equations.rs:151-169), with one step of iterative refinement against
+// the matrix itself:  v0 = L^-T L^-1 r;  rho = r - M.v0;  v = v0 + L^-T L^-1 rho.
+// Why: the factor is consumed through explicit inverses of its diagonal super-blocks (kernels_trsv.hip) -- a solve is
+// a handful of parallel mat-vecs instead of mp/128 dependent steps, but its backward error grows with the condition
+// of a super-block, and on the normal equations of the LAST iterations (x/z spanning 1e-9..1e9) that cost ~1 % of the
+// C4 members a visibly wrong direction (alpha 0.987 instead of 0.99995, one more iteration than the reference).  One
+// refinement step brings the solve back to the backward error of the reference's substitution.  R: nrhs x mp, in/out.
+static int chol_solve_refined(lpipm_ctx* c, int nrhs, double* R, const Batch& bt) {
+    hipStream_t st = c->st;
+    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = (e && e[0] == '0') ? 0 : 1; }
+    if (!c->refine) { LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt)); return LPIPM_OK; }
+    vec_rows_copy(c->mp, nrhs, c->R0, R, st, bt);
+    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt));
+    LP_HIP(launch_symv_residual(c->M0, c->mp, c->mp, nrhs, R, c->mp, c->R0, c->mp, c->Rho, c->mp, c->symv_ws, st, bt));
+    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, c->Rho, c->Y, st, bt));
+    vec_rows_add(c->mp, nrhs, R, c->Rho, st, bt);
+    LP_HIP(hipGetLastError());
+    return LPIPM_OK;
+}
+
 static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol) {
     VecArgs& v = c->va;
     // A.x and A^T.y at the current point (residual.rs:23,25)
@@ -556,7 +581,10 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const XRank* xr = c->colsplit ? &xr_ : nullptr;
     const Batch& bt = c->bt;
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
-    if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
+    if (chol) {
+        vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, bt);     // the matrix itself, for the refinement of the solves
+        LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
+    }
     else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
@@ -568,7 +596,7 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
         vec_add_rows((int)c->m, 2, v.R, c->mp, v.b, v.rP, st);
     }
     prof_mark(c, T_GEMV);
-    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 2, v.R, c->Y, st, bt));       // :221, :154
+    if (chol) LP_TRY(chol_solve_refined(c, 2, v.R, bt));                                    // :221, :154
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 2, v.R, v.potrf_info, st));   // :155-166
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 2, v.R, bt));              // :223
@@ -586,7 +614,7 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
         vec_add_rows((int)c->m, 1, v.R, c->mp, v.rP2, nullptr, st);
     }
     prof_mark(c, T_GEMV);
-    if (chol) LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, 1, v.R, c->Y, st, bt));
+    if (chol) LP_TRY(chol_solve_refined(c, 1, v.R, bt));
     else      LP_HIP(launch_qr_solve(c->M, c->mp, c->mp, c->tau, 1, v.R, v.potrf_info, st));
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 1, v.R, bt));
@@ -1183,6 +1211,29 @@ extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const doub
     LP_HIP(hipMemcpy2DAsync(V, m * sizeof(double), c->kR, (size_t)mp * sizeof(double), m * sizeof(double), nrhs,
                             hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_symv_residual(lpipm_ctx* c, uint64_t m, const double* M, int nrhs, const double* V, const double* R0,
+                                     double* Rho) {
+    if (!c || !M || !V || !R0 || !Rho || m == 0 || m > (1u << 20) || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    LP_HIP(hipSetDevice(c->device));
+    const int mp = (int)round_up(m, NB);
+    LP_TRY(kbuf_ensure(c, mp));
+    double *ws = nullptr, *vbuf = nullptr;
+    LP_HIP(hipMalloc((void**)&ws, symv_slab_doubles(mp) * sizeof(double)));
+    LP_HIP(hipMalloc((void**)&vbuf, (size_t)6 * mp * sizeof(double)));
+    LP_HIP(hipMemsetAsync(vbuf, 0, (size_t)6 * mp * sizeof(double), c->st));
+    LP_HIP(hipMemsetAsync(c->kM0, 0, (size_t)mp * mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpy2DAsync(c->kM0, (size_t)mp * sizeof(double), M, m * sizeof(double), m * sizeof(double), m, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpy2DAsync(vbuf, (size_t)mp * sizeof(double), V, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpy2DAsync(vbuf + 2 * mp, (size_t)mp * sizeof(double), R0, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st));
+    hipError_t e = launch_symv_residual(c->kM0, mp, mp, nrhs, vbuf, mp, vbuf + 2 * mp, mp, vbuf + 4 * mp, mp, ws, c->st);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(Rho, m * sizeof(double), vbuf + 4 * mp, (size_t)mp * sizeof(double), m * sizeof(double), nrhs, hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+    (void)hipFree(ws); (void)hipFree(vbuf);
+    LP_HIP(e);
     return LPIPM_OK;
 }
 

@@ -46,4 +46,9 @@ ctx = lp_amd.Context(0)
 L, info, _ = ctx.k_potrf(M)
 V, _ = ctx.k_chol_solve(m, rhs)
 report(f"GPU super={os.environ.get('LPIPM_SUPER', '1024')}", V[0])
+Lg = np.tril(L).astype(LD); Lor = np.tril(Lo).astype(LD)
+fres = lambda F: float(np.abs(np.tril(Ml - F @ F.T)).max() / np.abs(M).max())
+dM = np.sqrt(np.diag(M))
+fres_s = lambda F: float(np.abs(np.tril((Ml - F @ F.T) / np.outer(dM, dM))).max())     # scaled: |dM_ij| / sqrt(M_ii M_jj)
+print(f"  factorisation residual |M - L L^T|/|M|: gpu {fres(Lg):.2e} oracle {fres(Lor):.2e};  scaled by sqrt(M_ii M_jj): gpu {fres_s(Lg):.2e} oracle {fres_s(Lor):.2e}")
 print(f"  |L_gpu - L_oracle| / |L|: {np.abs(np.tril(L) - np.tril(Lo)).max() / np.abs(Lo).max():.2e}, info {info}; cond(M) ~ {np.linalg.cond(M):.2e}")

@@ -144,3 +144,17 @@ def test_qr_solve(ctx, m):
     Ms[1, :] = 0.0
     _, info, _ = ctx.k_qr_solve(Ms, R[:1])
     assert info != 0
+
+
+@pytest.mark.parametrize("m,nrhs", [(64, 1), (100, 2), (128, 1), (700, 2), (1024, 2), (1500, 1)])
+def test_symv_residual_reads_only_the_lower_triangle(ctx, m, nrhs):
+    """rho = r0 - M.v of the solve's refinement step (solver.hip chol_solve_refined): symmetric M given by its lower
+    triangle alone (the upper one is filled with garbage here), against numpy on the symmetric matrix."""
+    rng = np.random.default_rng(m + nrhs)
+    G = rng.standard_normal((m, m))
+    S = G + G.T
+    L = np.tril(S) + np.triu(rng.standard_normal((m, m)) * 1e6, 1)      # what the kernel sees
+    V = rng.standard_normal((nrhs, m)); R0 = rng.standard_normal((nrhs, m))
+    got = ctx.k_symv_residual(L, V, R0)
+    ref = R0 - V @ S
+    assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
