@@ -57,6 +57,7 @@ struct GemmK {
     int nwg;
     unsigned int* sk_claim;   // see GemmArgs
     int kc;                   // canonical summation chunk in k-tiles (0: plain running sum over the whole k-range)
+    double* C2;               // nullable: the final value of every tile is stored here too (same ldc)
     BatchK bk;
 };
 // LP blockIdx.z of a lockstep batch: per-LP pointers shifted (the tile list is shared)
@@ -64,6 +65,7 @@ __device__ __forceinline__ GemmK batch_shift(const GemmK& p0) {
     GemmK p = p0;
     p.P = batch_ptr(p0.P, p0.bk); p.Q = batch_ptr(p0.Q, p0.bk); p.s = batch_ptr(p0.s, p0.bk);
     p.C = batch_ptr(p0.C, p0.bk); p.ws = batch_ptr(p0.ws, p0.bk); p.sk_claim = batch_ptr(p0.sk_claim, p0.bk);
+    p.C2 = batch_ptr(p0.C2, p0.bk);
     return p;
 }
 
@@ -238,7 +240,7 @@ __device__ __forceinline__ void chunk_range(int o, int kc, int q, int KT, int& k
 // The software pipeline (next k-tile prefetched into registers while the current one is multiplied out of LDS) runs
 // across chunk boundaries; the hot inner loop is the plain k-tile loop and the chunk logic lives around it:
 //   touch(first)  at the start of a chunk's last k-tile: may issue loads that pull the C tile towards L2
-//   flush(first)  after a chunk's last k-tile: stores / adds the accumulators (the caller's business); the
+//   flush(first, last)  after a chunk's last k-tile: stores / adds the accumulators (the caller's business); the
 //                 accumulators restart from zero if more chunks follow.
 template <bool SCALE, typename FL, typename TC>
 __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], double (*ldsB)[TILE][LDS_STRIDE],
@@ -303,7 +305,7 @@ __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], d
         mfma_ktile(cur);
         if (more) lstore(cur ^ 1);
         asm volatile("" :: "v"(pf0), "v"(pf1));            // the touch loads have landed (and their registers are free) from here
-        flush(first);
+        flush(first, !more);
         if (more) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -356,10 +358,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         tile_store<4, 2>(cb, p.ldc, acc, p.alpha, p.beta, p.diag_pad_from >= 0 && ti == tj, ti * TILE + wr * 64 + fq,
                          p.diag_pad_from, fr, fq, wc * 32 - wr * 64);
     };
-    // C tile += chunk sum (canonical order: alpha == 1, beta == 0).  Two rounds of 16 values per lane: the registers of
+    // C tile += alpha * chunk sum.  Two rounds of 16 values per lane: the registers of
     // the staging and fragment values, dead at this point, hold the C values on their way in.
-    auto add_tile = [&](const d4 (&acc)[4][2], int ti, int tj) {
+    auto add_tile = [&](const d4 (&acc)[4][2], int ti, int tj, bool final_copy) {
         const __amdgpu_buffer_rsrc_t cr = c_rsrc(ti, tj);
+        const __amdgpu_buffer_rsrc_t cr2 = make_rsrc((final_copy ? p.C2 : p.C) + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             double cv[2][4][2];
@@ -376,8 +379,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nj = 0; nj < 2; ++nj)
-                        buf_store_d(cr, offC, (unsigned)((2 * h + m2) * 16 + 4 * r) * rowC + nj * 128,
-                                    cv[m2][r][nj] + acc[2 * h + m2][nj][r]);
+                    {
+                        const double v = p.alpha == 1.0 ? cv[m2][r][nj] + acc[2 * h + m2][nj][r] : fma(p.alpha, acc[2 * h + m2][nj][r], cv[m2][r][nj]);
+                        buf_store_d(cr, offC, (unsigned)((2 * h + m2) * 16 + 4 * r) * rowC + nj * 128, v);
+                        if (final_copy) buf_store_d(cr2, offC, (unsigned)((2 * h + m2) * 16 + 4 * r) * rowC + nj * 128, v);
+                    }
         }
     };
     // Touches every 128-B line of this wave's 64 x 32 part of the C tile (lane l: row l, columns 0 and 16), one k-tile
@@ -403,7 +409,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         d4 acc[4][2];
         zero(acc);
         tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq,
-                            p.kc, chunk_phase(tile, p.kc), [&](bool first) { if (first) store_tile(acc, ti, tj); else add_tile(acc, ti, tj); },
+                            p.kc, chunk_phase(tile, p.kc), [&](bool first, bool last) {
+                                if (first) store_tile(acc, ti, tj); else add_tile(acc, ti, tj, last && p.C2 != nullptr);
+                            },
                             [&](bool first, unsigned& pf0, unsigned& pf1) { if (!first) touch_tile(ti, tj, pf0, pf1); });
     }
     if (ntiles_dp == p.ntiles) return;
@@ -417,7 +425,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int ch = __builtin_amdgcn_readfirstlane(s_claim);
         __syncthreads();
         if (ch >= nchunks) break;
-        const int rt = ch / cpt, q = ch - rt * cpt;
+        // chunk-major order: the units in flight together are the same k-range of different tiles, which share the
+        // row panels of A in L2 (tile-major order would have every unit load two panels of its own)
+        const int nrem = p.ntiles - ntiles_dp;
+        const int q = ch / nrem, rt = ch - q * nrem;
         int kb, ke;
         if (p.kc > 0) chunk_range(chunk_phase(ntiles_dp + rt, p.kc), p.kc, q, KT, kb, ke);
         else { kb = q * SK_CHUNK; ke = kb + SK_CHUNK < KT ? kb + SK_CHUNK : KT; }
@@ -427,9 +438,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         d4 acc[4][2];
         zero(acc);
         tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq,
-                            0, 0, [&](bool) {
+                            0, 0, [&](bool, bool) {
             if (cpt == 1) { store_tile(acc, ti, tj); return; }   // the chunk is the whole tile
-            const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(p.ws + (long long)ch * (TILE * TILE), (unsigned)(TILE * TILE * sizeof(double)));
+            const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(p.ws + ((long long)rt * cpt + q) * (TILE * TILE), (unsigned)(TILE * TILE * sizeof(double)));
             const unsigned offW = (unsigned)(((wr * 64 + fq) * TILE + wc * 32 + fr) * sizeof(double));
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
             if (row == col + 1 && row >= p.diag_pad_from) v[1] = 1.0;
         }
         *(d2*)cp = v;
+        if (p.C2) *(d2*)(p.C2 + (long long)row * p.ldc + col) = v;
     }
 }
 
@@ -626,6 +638,7 @@ int gemm_streamk_nwg(int ntiles, int KT, int num_cu) {
     if (nwg < 1) nwg = 1;
     return (int)nwg;
 }
+bool gemm_streamk_split(int KT) { return streamk_cpt(KT) > 1; }
 size_t gemm_streamk_slabs(int ntiles, int KT, int nwg) {
     const int cpt = streamk_cpt(KT);
     const int nrem = ntiles - (ntiles / nwg) * nwg;
@@ -638,7 +651,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.C = a.C; k.ldc = a.ldc; k.KT = a.K / BK; k.alpha = a.alpha; k.beta = a.beta;
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg; k.bk = batch_k(a.batch);
-    k.sk_claim = a.sk_claim; k.kc = 0;
+    k.sk_claim = a.sk_claim; k.kc = 0; k.C2 = a.C2;
     const int B = a.batch.count;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
     if (!a.streamk) {   // one whole tile per workgroup
@@ -650,8 +663,9 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
         else                        hipLaunchKernelGGL((gemm_nt_tile_kernel<4, 4>), dim3(a.ntiles, 1, B), dim3(256), 0, st, k);
         return hipGetLastError();
     }
-    // A.D.A^T: canonical chunked summation (see the head of this file); alpha = 1, beta = 0 only
-    if (a.alpha != 1.0 || a.beta != 0.0 || !a.sk_claim) return hipErrorInvalidValue;
+    // canonical chunked summation (see the head of this file).  Data-parallel tiles take beta at their first chunk and
+    // add alpha * chunk afterwards; stream-K tiles get alpha and beta in the fix-up.
+    if (!a.sk_claim) return hipErrorInvalidValue;
     if (a.ldp >= (1 << 22) || a.ldq >= (1 << 22) || a.ldc >= (1 << 22)) return hipErrorInvalidValue;   // 128-row panels are 32-bit buffers
     if (a.s && a.ldp != a.ldq) return hipErrorInvalidValue;    // the scaled form is A.D.A^T: both operands are A
     k.kc = gemm_streamk_chunk(k.KT);
@@ -659,6 +673,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     if (k.kc == 0 && k.KT > SK_CHUNK) return hipErrorInvalidValue;
     const int cpt = streamk_cpt(k.KT);
     const int nrem = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
+    if (a.C2 && (cpt == 1 || a.beta != 0.0)) return hipErrorInvalidValue;   // the second copy comes from a tile's last flush / the fix-up
     if (nrem > 0) {
         if (cpt > 1 && !a.ws) return hipErrorInvalidValue;
         hipError_t em = B == 1 ? hipMemsetAsync(a.sk_claim, 0, sizeof(unsigned int), st)

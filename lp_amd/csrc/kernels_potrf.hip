@@ -359,77 +359,99 @@ long long* g_diag_stamps = nullptr;  // debug: device buffer of 8 cycle stamps f
 //   diag(j) -> panel solve(j) -> update of the REST OF THE OUTER PANEL only (K = 128, few tiles)
 // and the big trailing update runs once per outer panel with K = OUTER*128: 4x fewer read-modify-write
 // passes over the trailing matrix (at K = 128 that update is bound by the C-tile traffic, 16 flop/B).
-constexpr int OUTER = 4;
+constexpr int OUTER = POTRF_OUTER;
+
+hipError_t potrf_clear_info(int32_t* info, hipStream_t st, const Batch& bt) {
+    // (a finished LP of a batch has its info word cleared too: its status record already holds the value)
+    return bt.count == 1 ? hipMemsetAsync(info, 0, sizeof(int32_t), st)
+                         : hipMemset2DAsync(info, (size_t)bt.stride, 0, sizeof(int32_t), (size_t)bt.count, st);
+}
+
+// The dependent chain of one outer panel [J0, J1) of 128-blocks: diag(j) -> panel solve(j) (all rows below) -> update
+// of the rest of the outer panel's columns (K = 128, few tiles).
+hipError_t potrf_panel_chain(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
+                             const Batch& bt, int J0, int J1) {
+    hipError_t e;
+    const int nb = mp / NB;
+    for (int j = J0; j < J1; ++j) {
+        const int64_t o = (int64_t)j * NB;
+        double* diag = M + o * ld + o;
+        double* linv = plan.blk_inv(j);
+        const int ldinv = plan.blk_ld(j);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, bt.count), dim3(DT), 0, st, diag, (long long)ld, linv,
+                           plan.blk_invT(j), (long long)ldinv, info, (int)o,
+                           (long long*)(j == 0 ? g_diag_stamps : nullptr), batch_k(bt));
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int rem = nb - j - 1;
+        if (rem <= 0) break;
+        double* panel = M + (o + NB) * ld + o;   // rows below block j, column block j
+        GemmArgs t{};
+        t.P = panel; t.ldp = ld; t.Q = linv; t.ldq = ldinv; t.s = nullptr;
+        t.C = panel; t.ldc = ld; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
+        // few tiles -> latency-bound: 32-row x 128-col tiles put 4x as many CUs on the panel, and a
+        // workgroup still owns whole rows, so the product may overwrite its own input
+        t.tile_edge = 32;
+        t.ntiles = 4 * rem; t.tiles_lower = 0; t.ntj = 1; t.tile_list = nullptr;
+        t.diag_pad_from = -1; t.ws = nullptr; t.nwg = t.ntiles; t.batch = bt;
+        e = launch_gemm_nt(t, st);
+        if (e != hipSuccess) return e;
+        const int ncols = J1 - j - 1;            // column blocks of the outer panel right of j
+        if (ncols > 0) {
+            // rows j+1..nb x columns j+1..J1-1 -= L[rows, j] . L[cols, j]^T  (rectangular grid of
+            // 64x64 tiles; the few tiles above the diagonal are computed too and never read)
+            GemmArgs c{};
+            c.P = panel; c.ldp = ld; c.Q = panel; c.ldq = ld; c.s = nullptr;
+            c.C = M + (o + NB) * ld + (o + NB); c.ldc = ld; c.K = NB; c.alpha = -1.0; c.beta = 1.0;
+            c.tile_edge = 64; c.tiles_lower = 0; c.ntj = 2 * ncols; c.ntiles = (2 * rem) * (2 * ncols);
+            c.tile_list = nullptr; c.diag_pad_from = -1; c.ws = nullptr; c.nwg = c.ntiles; c.batch = bt;
+            e = launch_gemm_nt(c, st);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+// Right-looking trailing update behind the outer panel [J0, J1): A22 -= L21 . L21^T with K = (J1 - J0) * 128.
+hipError_t potrf_trailing_update(double* M, int64_t ld, int mp, hipStream_t st, const Batch& bt, int J0, int J1) {
+    const int nb = mp / NB;
+    const int remT = nb - J1;                    // trailing blocks beyond the outer panel
+    if (remT <= 0) return hipSuccess;
+    const int64_t oJ0 = (int64_t)J0 * NB, oJ1 = (int64_t)J1 * NB;
+    GemmArgs u{};
+    u.P = M + oJ1 * ld + oJ0; u.ldp = ld; u.Q = u.P; u.ldq = ld; u.s = nullptr;
+    u.C = M + oJ1 * ld + oJ1; u.ldc = ld; u.K = (J1 - J0) * NB; u.alpha = -1.0; u.beta = 1.0;
+    u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
+    // 64x64 tiles (4 workgroups per CU) until the 128x128 ones would fill the chip's 512 slots about twice:
+    // below that a launch lasts one K = 512 tile (~150 us at 128, ~60 at 64) whatever its tile count
+    // (factorisation at m = 4096: 2400 -> 2311 us)
+    if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
+    else                             { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
+    u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles; u.batch = bt;
+    return launch_gemm_nt(u, st);
+}
+
+// inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
+// grouped launch of stage A (T^T = Inv11^T.L21^T) then stage B (Inv21 = -Inv22.T and its transpose)
+hipError_t potrf_superblock_inverses(const FactorPlan& plan, hipStream_t st, const Batch& bt) {
+    for (const auto& stg : plan.stages) {
+        hipError_t e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st, bt, plan.merge_edge);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
                         const Batch& bt) {
-    // (a finished LP of a batch has its info word cleared too: its status record already holds the value)
-    hipError_t e = bt.count == 1 ? hipMemsetAsync(info, 0, sizeof(int32_t), st)
-                                 : hipMemset2DAsync(info, (size_t)bt.stride, 0, sizeof(int32_t), (size_t)bt.count, st);
+    hipError_t e = potrf_clear_info(info, st, bt);
     if (e != hipSuccess) return e;
     const int nb = mp / NB;
     for (int J0 = 0; J0 < nb; J0 += OUTER) {
         const int J1 = J0 + OUTER < nb ? J0 + OUTER : nb;
-        for (int j = J0; j < J1; ++j) {
-            const int64_t o = (int64_t)j * NB;
-            double* diag = M + o * ld + o;
-            double* linv = plan.blk_inv(j);
-            const int ldinv = plan.blk_ld(j);
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, 1, bt.count), dim3(DT), 0, st, diag, (long long)ld, linv,
-                               plan.blk_invT(j), (long long)ldinv, info, (int)o,
-                               (long long*)(j == 0 ? g_diag_stamps : nullptr), batch_k(bt));
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            const int rem = nb - j - 1;
-            if (rem <= 0) break;
-            double* panel = M + (o + NB) * ld + o;   // rows below block j, column block j
-            GemmArgs t{};
-            t.P = panel; t.ldp = ld; t.Q = linv; t.ldq = ldinv; t.s = nullptr;
-            t.C = panel; t.ldc = ld; t.K = NB; t.alpha = 1.0; t.beta = 0.0;
-            // few tiles -> latency-bound: 32-row x 128-col tiles put 4x as many CUs on the panel, and a
-            // workgroup still owns whole rows, so the product may overwrite its own input
-            t.tile_edge = 32;
-            t.ntiles = 4 * rem; t.tiles_lower = 0; t.ntj = 1; t.tile_list = nullptr;
-            t.diag_pad_from = -1; t.ws = nullptr; t.nwg = t.ntiles; t.batch = bt;
-            e = launch_gemm_nt(t, st);
-            if (e != hipSuccess) return e;
-            const int ncols = J1 - j - 1;            // column blocks of the outer panel right of j
-            if (ncols > 0) {
-                // rows j+1..nb x columns j+1..J1-1 -= L[rows, j] . L[cols, j]^T  (rectangular grid of
-                // 64x64 tiles; the few tiles above the diagonal are computed too and never read)
-                GemmArgs c{};
-                c.P = panel; c.ldp = ld; c.Q = panel; c.ldq = ld; c.s = nullptr;
-                c.C = M + (o + NB) * ld + (o + NB); c.ldc = ld; c.K = NB; c.alpha = -1.0; c.beta = 1.0;
-                c.tile_edge = 64; c.tiles_lower = 0; c.ntj = 2 * ncols; c.ntiles = (2 * rem) * (2 * ncols);
-                c.tile_list = nullptr; c.diag_pad_from = -1; c.ws = nullptr; c.nwg = c.ntiles; c.batch = bt;
-                e = launch_gemm_nt(c, st);
-                if (e != hipSuccess) return e;
-            }
-        }
-        const int remT = nb - J1;                    // trailing blocks beyond the outer panel
-        if (remT > 0) {
-            const int64_t oJ0 = (int64_t)J0 * NB, oJ1 = (int64_t)J1 * NB;
-            GemmArgs u{};
-            u.P = M + oJ1 * ld + oJ0; u.ldp = ld; u.Q = u.P; u.ldq = ld; u.s = nullptr;
-            u.C = M + oJ1 * ld + oJ1; u.ldc = ld; u.K = (J1 - J0) * NB; u.alpha = -1.0; u.beta = 1.0;
-            u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
-            // 64x64 tiles (4 workgroups per CU) until the 128x128 ones would fill the chip's 512 slots about twice:
-            // below that a launch lasts one K = 512 tile (~150 us at 128, ~60 at 64) whatever its tile count
-            // (factorisation at m = 4096: 2400 -> 2311 us)
-            if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
-            else                             { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
-            u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles; u.batch = bt;
-            e = launch_gemm_nt(u, st);
-            if (e != hipSuccess) return e;
-        }
+        if ((e = potrf_panel_chain(M, ld, mp, plan, info, st, bt, J0, J1)) != hipSuccess) return e;
+        if ((e = potrf_trailing_update(M, ld, mp, st, bt, J0, J1)) != hipSuccess) return e;
     }
-    // inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
-    // grouped launch of stage A (T^T = Inv11^T.L21^T) then stage B (Inv21 = -Inv22.T and its transpose)
-    for (const auto& stg : plan.stages) {
-        e = launch_gemm_grouped(plan.descs_dev + stg.first, stg.second, st, bt, plan.merge_edge);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    return potrf_superblock_inverses(plan, st, bt);
 }
 
 }  // namespace lpipm

@@ -6,6 +6,7 @@
 // in a device block `S`, reductions are two-stage (per-workgroup partials in `red`, summed in
 // fixed order by the next scalar kernel) and therefore bitwise reproducible.
 // Each kernel cites the reference lines whose arithmetic (and operation order) it reproduces.
+#include <cstdlib>
 #include "vec_kernels.hpp"
 
 namespace lpipm {
@@ -67,6 +68,7 @@ __device__ __forceinline__ bool vbatch(VecArgs& a, bool check_done) {
     a.Ax = batch_ptr(a.Ax, bk); a.W = batch_ptr(a.W, bk); a.R = batch_ptr(a.R, bk); a.ATpart = batch_ptr(a.ATpart, bk);
     a.S = batch_ptr(a.S, bk); a.red = batch_ptr(a.red, bk); a.status = batch_ptr(a.status, bk);
     a.potrf_info = batch_ptr(a.potrf_info, bk); a.flags = batch_ptr(a.flags, bk); a.done = batch_ptr(a.done, bk);
+    a.skip_refine = batch_ptr(a.skip_refine, bk);
     a.done_chk = batch_ptr(a.done_chk, bk);
     return true;
 }
@@ -188,7 +190,9 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
     st->potrf_info = *a.potrf_info;
     st->flags = *a.flags;
     // what ends the loop of solve_normal_form (mod.rs:215, :231-233): from here on the LP's kernels are skipped
-    if (!is_init && (status != ST_UNFINISHED || *a.potrf_info != 0 || (*a.flags & FLAG_NAN_PQ))) *a.done = 1;
+    const bool finished = !is_init && (status != ST_UNFINISHED || *a.potrf_info != 0 || (*a.flags & FLAG_NAN_PQ));
+    if (finished) *a.done = 1;
+    *a.skip_refine = (finished || !(imu <= a.refine_below)) ? 1 : 0;
     // next get_delta (feasible_point.rs:119-125)
     const double gamma = ip_next ? 1.0 : 0.0;
     const double eta = ip_next ? 1.0 : 1.0 - gamma;
@@ -430,6 +434,10 @@ static int cross(const VecArgs& a, const XRank* xr, int first, int count, int is
     if (!a.gs || !xr) return 0;
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, st, a, first, count, is_min, flag_slot);
     return xr->fn(xr->self, a.gs + red_first, red_count, is_min);
+}
+double refine_below() {
+    static const double v = getenv("LPIPM_REFINE_BELOW") ? atof(getenv("LPIPM_REFINE_BELOW")) : REFINE_BELOW_RHO_MU;
+    return v;
 }
 int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);

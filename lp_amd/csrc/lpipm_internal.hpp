@@ -99,6 +99,7 @@ struct GemmArgs {
     unsigned int* sk_claim;     // stream-K: the device word through which the chunks of the remainder tiles are claimed
                                 //   (workgroups that finish their data-parallel tiles early take more of them); slabs are
                                 //   indexed by chunk, so the sums do not depend on who computed what
+    double*       C2;           // stream-K launches whose tiles are all split (ntiles < nwg): final values stored here too
     int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
     Batch         batch;        // lockstep batch (every pointer above except tile_list is per LP)
 };
@@ -108,6 +109,8 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st);
 // work on num_cu CUs, and the number of TILE x TILE slabs ws must hold for a given workgroup count
 int gemm_streamk_chunk(int KT);
 size_t gemm_streamk_slabs(int ntiles, int KT, int nwg);
+bool gemm_streamk_split(int KT);     // contraction long enough to be cut into chunks (only then can GemmArgs::C2 be used)
+int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 // One output tile (128x128, or 64x64 with edge = 64) of a grouped launch: C = alpha * P[0:E, kb:ke) . Q[0:E, kb:ke)^T
 // (k-range in units of BK), each tile with its own operands.
 struct GemmTileDesc {
@@ -119,8 +122,6 @@ struct GemmTileDesc {
 // descs_dev holds LP 0's pointers; LP z of a batch shifts P, Q, C by z*stride.
 hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt = Batch{},
                                int edge = 128);
-// Workgroup count the stream-K ADA^T launch wants for ntiles x KT work.
-int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
 
 // ---------------------------------------------------------------- factor plan (kernels_trsv.hip)
 // The factor L is consumed through explicit inverses of its diagonal SUPER-blocks (up to 1024 wide):
@@ -160,6 +161,14 @@ void factor_plan_destroy(FactorPlan& plan);
 // first non-positive pivot.
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
                         const Batch& bt = Batch{});
+
+// The pieces of launch_potrf, for the factorisation that runs beside A.D.A^T (solver.hip, enqueue_factor_overlapped):
+constexpr int POTRF_OUTER = 4;   // 128-blocks per outer panel
+hipError_t potrf_clear_info(int32_t* info, hipStream_t st, const Batch& bt);
+hipError_t potrf_panel_chain(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
+                             const Batch& bt, int J0, int J1);
+hipError_t potrf_trailing_update(double* M, int64_t ld, int mp, hipStream_t st, const Batch& bt, int J0, int J1);
+hipError_t potrf_superblock_inverses(const FactorPlan& plan, hipStream_t st, const Batch& bt);
 
 // ---------------------------------------------------------------- triangular solves (kernels_trsv.hip)
 // R[r] <- L^-T L^-1 R[r], r < nrhs (1|2); R is nrhs x mp (row stride mp); Yscratch: nrhs x mp.

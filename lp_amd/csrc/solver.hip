@@ -57,8 +57,24 @@ struct lpipm_ctx {
     double *tau = nullptr, *ktau = nullptr;   // Householder scalars of the QR arms
     double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
     double *M0 = nullptr, *R0 = nullptr, *Rho = nullptr, *symv_ws = nullptr;   // refinement of the Cholesky solve
-    int refine = -1;             // -1: decide from the environment at first use (LPIPM_REFINE=0 switches it off)
+    // factorisation beside A.D.A^T (enqueue_factor_overlapped): two CU-masked streams, column groups of the tile list
+    hipStream_t st_a = nullptr, st_b = nullptr;
+    int overlap_cus = 0;                 // CUs per XCC reserved for the chain stream (0: no masked streams)
+    bool overlap = false;                // this problem can be factorised beside its A.D.A^T (geometry)
+    bool factor_in_head = false;         // ... and the current solve does so (Cholesky arm, no column split, no graph replay)
+    uint64_t overlap_sections = 0;       // profiling: sections enqueued in this solve
+    std::vector<int> grp_off, grp_nt;    // tile sub-list of every column group (outer panel of the factorisation)
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
+    int refine = -1;             // -1: decide from the environment at first use.  2 (default): every solve of every iteration is
+                                 //   refined; 0: never (LPIPM_REFINE=0); 1: only from mu / mu_0 <= refine_below() on (LPIPM_REFINE=1).
+                                 //   Measured on the 256 C4 members: "never" and every selective threshold (1e-2, 1e-1, 1) leave
+                                 //   some member with a poor step (another member each time: 202 and 217, 217, 89, 160) and one
+                                 //   iteration more than the oracle; "always" leaves none.
+    bool refine_now = false;     // the iteration being enqueued refines its solves (host mirror of the LPs' skip_refine words)
     int2* tile_list = nullptr;
+    int2* tile_list_grp = nullptr;      // the same tiles grouped by column group (behind tile_list in one allocation)
+    size_t ws_slabs = 0;                // stream-K slabs (TILE x TILE doubles each) the A.D.A^T / update launches may need
     unsigned int* sk_claim = nullptr;   // claim word of the dynamic stream-K chunks of A.D.A^T
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
@@ -83,7 +99,7 @@ struct lpipm_ctx {
     int batch_concurrency = 0;   // 0 = auto
     int lockstep_max = -1;       // lpipm_solve_batch: -1 auto, 0 never group same-shape members, > 0 largest group
     // captured iteration (hipGraph): one executable graph per (ip, options) key, valid while the buffers live
-    struct IterGraph { int ip; double alpha0, tol; hipGraphExec_t exec; };
+    struct IterGraph { int ip; int refine; double alpha0, tol; hipGraphExec_t exec; };
     std::vector<IterGraph> graphs;
     int use_graph = -1;          // -1: decide from the environment at first use
     bool no_speculate = false;
@@ -164,6 +180,16 @@ static void prof_collect(lpipm_ctx* c, size_t upto = (size_t)-1) {
     c->nmarks -= upto;
 }
 
+// A.D.A^T time of one completed overlapped section (its events have completed): sum over the column groups
+static void prof_collect_overlap(lpipm_ctx* c, uint64_t section) {
+    if (!c->profiling || !c->factor_in_head) return;
+    hipEvent_t* ev = c->ev_adat.data() + (section & 1) * 2;
+    for (size_t g = 0; g < c->grp_nt.size(); ++g) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[4 * g], ev[4 * g + 1]) == hipSuccess) c->tag_ms[T_ADAT] += ms;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" void lpipm_default_opts(lpipm_opts* o) {  // interior_point/mod.rs:50-60
     if (!o) return;
@@ -242,6 +268,32 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
         return LPIPM_ERR_HIP;
     }
     c->status_cap = 1;
+    // Two CU-masked streams for the factorisation that runs beside A.D.A^T (enqueue_factor_overlapped).  Mask bit i is
+    // CU i/8 of XCC i%8 (scripts/diag/cu_mask_probe.cpp; an XCC with no bit set would be unrestricted): the chain stream
+    // gets CUs 0..R-1 of every XCC, the throughput stream the rest.  OFF by default -- measured at C3 the scheme is
+    // correct but not faster (163 vs 175 it/s; A.D.A^T in eight stream-K pieces on 224 CUs costs what the
+    // hidden chain saves): LPIPM_OVERLAP=1 switches it on, LPIPM_OVERLAP_CUS=R sets R (default 4).  Only on the
+    // 8 x 32 CU layout it was measured on.
+    {
+        const char* on = getenv("LPIPM_OVERLAP");
+        int R = 4;
+        if (const char* e = getenv("LPIPM_OVERLAP_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 16) R = v; }
+        if (on && on[0] == '1' && c->num_cu == 256) {
+            uint32_t ma[8], mb[8];
+            for (int w = 0; w < 8; ++w) { ma[w] = 0; mb[w] = 0; }
+            for (int i = 0; i < 256; ++i) ((i / 8) < R ? mb : ma)[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&c->st_a, 8, ma) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&c->st_b, 8, mb) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess) {
+                c->overlap_cus = R;
+            } else {
+                (void)hipGetLastError();
+                if (c->st_a) (void)hipStreamDestroy(c->st_a);
+                if (c->st_b) (void)hipStreamDestroy(c->st_b);
+                c->st_a = c->st_b = nullptr;
+            }
+        }
+    }
     *out = c;
     return LPIPM_OK;
 }
@@ -263,6 +315,12 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
     if (c->ev_status) (void)hipEventDestroy(c->ev_status);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_ready) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_chain) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_adat) (void)hipEventDestroy(e);
+    if (c->st_a) { (void)hipStreamSynchronize(c->st_a); (void)hipStreamDestroy(c->st_a); }
+    if (c->st_b) { (void)hipStreamSynchronize(c->st_b); (void)hipStreamDestroy(c->st_b); }
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
@@ -272,6 +330,21 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
 // renumbered so that 64 consecutive tiles run on one XCD (one L2): full off-diagonal 8x8 super-blocks
 // come first, each exactly one such chunk (16 row panels of A feed 64 tiles); the triangular
 // diagonal super-blocks (36 tiles each) follow and are the ones that straddle chunk boundaries.
+// The same tiles ordered for the factorisation that runs beside A.D.A^T: column group g (tile columns 4g .. 4g+3, one
+// outer panel of the factorisation) is one contiguous sub-list; inside it row by row, so that consecutive stream-K
+// claims of one k-range share a row panel of A.
+static std::vector<int2> adat_tile_order_grouped(int nt, std::vector<int>& off, std::vector<int>& cnt) {
+    std::vector<int2> v;
+    off.clear(); cnt.clear();
+    for (int g = 0; g * POTRF_OUTER < nt; ++g) {
+        off.push_back((int)v.size());
+        const int c0 = g * POTRF_OUTER, c1 = c0 + POTRF_OUTER < nt ? c0 + POTRF_OUTER : nt;
+        for (int ti = c0; ti < nt; ++ti)
+            for (int tj = c0; tj < c1 && tj <= ti; ++tj) v.push_back(make_int2(ti, tj));
+        cnt.push_back((int)v.size() - off.back());
+    }
+    return v;
+}
 static std::vector<int2> adat_tile_order(int nt) {
     std::vector<int2> v;
     v.reserve((size_t)nt * (nt + 1) / 2);
@@ -323,6 +396,7 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.S = ar.take<double>(64); v.red = ar.take<double>((size_t)RED_SLOTS * RED_STRIDE);
     v.status = ar.take<StatusRec>(1);
     v.potrf_info = ar.take<int32_t>(1); v.flags = ar.take<int>(1); v.done = ar.take<int>(1);
+    v.skip_refine = ar.take<int>(1);
     c->M = ar.take<double>(mp * mp);
     LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->mp), merge_edge_for(c->B)));
     c->M0 = ar.take<double>(mp * mp);
@@ -332,8 +406,8 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
     c->sk_claim = ar.take<unsigned int>(1);
-    // stream-K chunk slabs of A.D.A^T (tiles that do not divide over the workgroups)
-    c->ws = ar.take<double>(gemm_streamk_slabs(c->ntiles, c->npa / BK, c->adat_nwg) * TILE * TILE);
+    // stream-K chunk slabs of A.D.A^T (tiles that do not divide over the workgroups) and of the factorisation's updates
+    c->ws = ar.take<double>(c->ws_slabs * TILE * TILE);
     return LPIPM_OK;
 }
 
@@ -392,6 +466,33 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
             c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu / count);
             if (c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
         }
+        c->ws_slabs = gemm_streamk_slabs(c->ntiles, npa / BK, c->adat_nwg);
+        // Factorisation beside A.D.A^T: single LP, big enough that A.D.A^T can hide the factorisation's chain
+        c->overlap = count == 1 && c->st_a != nullptr && mp >= 2048;
+        std::vector<int2> grouped;
+        if (c->overlap) {
+            grouped = adat_tile_order_grouped(nt, c->grp_off, c->grp_nt);
+            const int wg = 2 * (c->num_cu - 8 * c->overlap_cus);
+            for (size_t g = 0; g < c->grp_nt.size(); ++g) {
+                const size_t s1 = gemm_streamk_slabs(c->grp_nt[g], npa / BK, gemm_streamk_nwg(c->grp_nt[g], npa / BK, wg / 2));
+                const int ku = (int)g * POTRF_OUTER * NB / BK;
+                const size_t s2 = ku ? gemm_streamk_slabs(c->grp_nt[g], ku, gemm_streamk_nwg(c->grp_nt[g], ku, wg / 2)) : 0;
+                if (s1 > c->ws_slabs) c->ws_slabs = s1;
+                if (s2 > c->ws_slabs) c->ws_slabs = s2;
+            }
+            while (c->ev_ready.size() < c->grp_nt.size()) {
+                hipEvent_t e1, e2, e3, e4;
+                LP_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                LP_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+                LP_HIP(hipEventCreate(&e3));
+                LP_HIP(hipEventCreate(&e4));
+                c->ev_ready.push_back(e1); c->ev_chain.push_back(e2); c->ev_adat.push_back(e3); c->ev_adat.push_back(e4);
+                hipEvent_t e5, e6;      // second set: the head of iteration k+1 is enqueued before iteration k's times are read
+                LP_HIP(hipEventCreate(&e5));
+                LP_HIP(hipEventCreate(&e6));
+                c->ev_adat.push_back(e5); c->ev_adat.push_back(e6);
+            }
+        }
         Arena measure;
         LP_TRY(layout_problem(c, measure, false));
         c->bstride = round_up(measure.off, 4096);
@@ -401,9 +502,12 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         Arena real;
         real.base = c->arena;
         LP_TRY(layout_problem(c, real, true));
-        LP_HIP(hipMalloc((void**)&c->tile_list, order.size() * sizeof(int2)));
+        LP_HIP(hipMalloc((void**)&c->tile_list, (order.size() + grouped.size()) * sizeof(int2)));
         LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-        LP_HIP(hipStreamSynchronize(st));  // `order` must outlive the copy
+        c->tile_list_grp = c->tile_list + order.size();
+        if (!grouped.empty())
+            LP_HIP(hipMemcpyAsync(c->tile_list_grp, grouped.data(), grouped.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        LP_HIP(hipStreamSynchronize(st));  // the lists must outlive the copies
         if ((size_t)count > c->status_cap) {
             if (c->status_host) (void)hipHostFree(c->status_host);
             c->status_host = nullptr; c->status_cap = 0;
@@ -412,7 +516,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         }
         VecArgs& v = c->va;
         v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
-        v.bcount = count; v.bstride = (long long)c->bstride;
+        v.bcount = count; v.bstride = (long long)c->bstride; v.refine_below = refine_below();
     } else {
         // same padded geometry: clear the whole state, so no stale (possibly non-finite) value of a
         // previous problem can sit in a padding lane
@@ -496,16 +600,85 @@ static hipError_t ctx_gemv_t(lpipm_ctx* c, int nrhs, const double* V, const Batc
     return launch_slack_t(c->ns, c->nx, nrhs, c->nsplit, V, c->mp, c->ATpart, c->np, c->st, bt);
 }
 
-// M = A . diag(dinv) . A^T, lower tiles (newton_equations.rs:54-57)
-static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
+// M = A . diag(dinv) . A^T, lower tiles (newton_equations.rs:54-57); a second copy of it goes to M0 (the matrix the
+// refined Cholesky solves take their residuals against: M itself is factorised in place)
+static GemmArgs adat_args(lpipm_ctx* c, const Batch& bt) {
     GemmArgs g{};
     g.P = c->A; g.ldp = c->npa; g.Q = c->A; g.ldq = c->npa; g.s = c->va.dinv;
     g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
     g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt; g.sk_claim = c->sk_claim; g.streamk = 1;
+    g.C2 = gemm_streamk_split(c->npa / BK) ? c->M0 : nullptr;
+    return g;
+}
+static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
+    const GemmArgs g = adat_args(c, bt);
     hipError_t e = launch_gemm_nt(g, c->st);
     if (e != hipSuccess) return e;
-    return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
+    e = launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
+    if (e != hipSuccess) return e;
+    if (g.C2) return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M0, c->mp, c->st, bt);
+    vec_copy_lower(c->M, c->M0, c->mp, c->mp, c->st, bt);     // short contraction: one store per tile, copied afterwards
+    return hipGetLastError();
+}
+
+// The normal equations AND their Cholesky factor, the factorisation running beside A.D.A^T (single LP, m >= 2048).
+// Why: the factorisation is a chain of 32 (m = 4096) dependent steps -- one 128 x 128 diagonal block on ONE CU
+// (34 us), its panel solve, the update of the next block -- that no arrangement of launches or device-side flags
+// makes shorter (a hand-off costs more than the 1.5 us kernel boundary it replaces, MI355X_MICROARCH.md price list):
+// 1.8 of its 2.3 ms keep 1-30 of 256 CUs busy.  So it is given other work to hide behind -- the 2.4 ms of A.D.A^T:
+//   * A.D.A^T is produced in COLUMN GROUPS (tile columns 4g .. 4g+3 = one outer panel of the factorisation), one
+//     stream-K launch per group on the throughput stream (CU mask: all but R CUs per XCC);
+//   * the factorisation is left-looking at the outer-panel level: before panel g is factorised, its column group gets
+//     all updates of the panels before it in ONE product (K = 512 g, the same stream-K kernel, alpha = -1, beta = 1),
+//     also on the throughput stream; inside a panel the chain is what it was (potrf_panel_chain), on the chain
+//     stream (CU mask: the R reserved CUs per XCC -- a diagonal-block kernel needs a whole CU's LDS, and on a chip
+//     full of 2-ms A.D.A^T workgroups it would wait for one);
+//   * events: group g ready (throughput -> chain), panel g done (chain -> throughput, for the update of group g+1).
+// The results are those of the same factorisation run alone (fixed summation orders everywhere).
+static int enqueue_factor_overlapped(lpipm_ctx* c, const Batch& bt) {
+    hipStream_t sm = c->st, sa = c->st_a, sb = c->st_b;
+    const int ng = (int)c->grp_nt.size();
+    const int wg_cus = c->num_cu - 8 * c->overlap_cus;
+    LP_HIP(hipEventRecord(c->ev_fork, sm));
+    LP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+    LP_HIP(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    LP_HIP(potrf_clear_info(c->va.potrf_info, sb, bt));
+    const bool timed = c->profiling != 0;
+    hipEvent_t* ev = c->ev_adat.data() + (c->overlap_sections & 1) * 2;   // [4 g + 2 parity + {begin, end}]
+    for (int g = 0; g < ng; ++g) {
+        const int J0 = g * POTRF_OUTER, J1 = J0 + POTRF_OUTER < c->mp / NB ? J0 + POTRF_OUTER : c->mp / NB;
+        // throughput stream: column group g of A.D.A^T (+ its slack diagonal), second copy to M0
+        GemmArgs a = adat_args(c, bt);
+        a.tile_list = c->tile_list_grp + c->grp_off[g]; a.ntiles = c->grp_nt[g];
+        a.nwg = gemm_streamk_nwg(a.ntiles, c->npa / BK, wg_cus);
+        if (timed) LP_HIP(hipEventRecord(ev[4 * g], sa));
+        LP_HIP(launch_gemm_nt(a, sa));
+        if (c->ns > J0 * NB) {
+            const int r0 = J0 * NB, cnt = (c->ns < J1 * NB ? c->ns : J1 * NB) - r0;
+            LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
+            LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M0 + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
+        }
+        if (timed) LP_HIP(hipEventRecord(ev[4 * g + 1], sa));
+        if (g > 0) {   // ... minus what the panels before it contribute: C -= L[rows, 0:K) . L[cols, 0:K)^T
+            LP_HIP(hipStreamWaitEvent(sa, c->ev_chain[g - 1], 0));
+            GemmArgs u{};
+            u.P = c->M; u.ldp = c->mp; u.Q = c->M; u.ldq = c->mp; u.s = nullptr;
+            u.C = c->M; u.ldc = c->mp; u.K = J0 * NB; u.alpha = -1.0; u.beta = 1.0;
+            u.ntiles = c->grp_nt[g]; u.tiles_lower = 1; u.tile_list = c->tile_list_grp + c->grp_off[g];
+            u.diag_pad_from = -1; u.ws = c->ws; u.batch = bt; u.sk_claim = c->sk_claim; u.streamk = 1;
+            u.nwg = gemm_streamk_nwg(u.ntiles, u.K / BK, wg_cus);
+            LP_HIP(launch_gemm_nt(u, sa));
+        }
+        LP_HIP(hipEventRecord(c->ev_ready[g], sa));
+        // chain stream: panel g
+        LP_HIP(hipStreamWaitEvent(sb, c->ev_ready[g], 0));
+        LP_HIP(potrf_panel_chain(c->M, c->mp, c->mp, c->plan, c->va.potrf_info, sb, bt, J0, J1));
+        LP_HIP(hipEventRecord(c->ev_chain[g], sb));
+    }
+    LP_HIP(hipStreamWaitEvent(sm, c->ev_chain[ng - 1], 0));    // everything on the throughput stream precedes it
+    LP_HIP(potrf_superblock_inverses(c->plan, sm, bt));
+    return LPIPM_OK;
 }
 
 // v = M^-1 r through the Cholesky factor (newton_equations.rs:151-169), with one step of iterative refinement against
@@ -517,13 +690,14 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
 // refinement step brings the solve back to the backward error of the reference's substitution.  R: nrhs x mp, in/out.
 static int chol_solve_refined(lpipm_ctx* c, int nrhs, double* R, const Batch& bt) {
     hipStream_t st = c->st;
-    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = (e && e[0] == '0') ? 0 : 1; }
-    if (!c->refine) { LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt)); return LPIPM_OK; }
-    vec_rows_copy(c->mp, nrhs, c->R0, R, st, bt);
+    if (!c->refine_now) { LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt)); return LPIPM_OK; }
+    // the refinement's launches skip an LP whose own word says so (a finished one, or one that does not need it yet)
+    const Batch br = c->refine == 2 ? bt : Batch{bt.count, bt.stride, c->va.skip_refine};
+    vec_rows_copy(c->mp, nrhs, c->R0, R, st, br);
     LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt));
-    LP_HIP(launch_symv_residual(c->M0, c->mp, c->mp, nrhs, R, c->mp, c->R0, c->mp, c->Rho, c->mp, c->symv_ws, st, bt));
-    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, c->Rho, c->Y, st, bt));
-    vec_rows_add(c->mp, nrhs, R, c->Rho, st, bt);
+    LP_HIP(launch_symv_residual(c->M0, c->mp, c->mp, nrhs, R, c->mp, c->R0, c->mp, c->Rho, c->mp, c->symv_ws, st, br));
+    LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, c->Rho, c->Y, st, br));
+    vec_rows_add(c->mp, nrhs, R, c->Rho, st, br);
     LP_HIP(hipGetLastError());
     return LPIPM_OK;
 }
@@ -562,12 +736,20 @@ static int enqueue_head(lpipm_ctx* c) {
     vh.done_chk = c->bt_head.done;
     prof_mark(c, T_VEC);
     vec_pred_setup(vh, st);
+    if (c->factor_in_head) {   // A.D.A^T and the Cholesky factorisation side by side (newton_equations.rs:55-57, :129-131)
+        prof_mark(c, T_VEC);
+        LP_TRY(enqueue_factor_overlapped(c, c->bt_head));
+        prof_mark(c, T_POTRF);
+        c->overlap_sections++;
+        return LPIPM_OK;
+    }
     prof_mark(c, T_VEC, true);
     LP_HIP(run_adat(c, c->bt_head));                                       // newton_equations.rs:55-57
     if (c->colsplit && c->world > 1) {                                     // n-split: M = sum_g A_g D_g A_g^T
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
         LP_TRY(ctx_allreduce(c, c->mpack, c->mpack_count, 0));
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 1, st);
+        vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, c->bt_head);         // the summed matrix, for the refined solves
     }
     prof_mark(c, T_ADAT, true);
     return LPIPM_OK;
@@ -581,11 +763,9 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const XRank* xr = c->colsplit ? &xr_ : nullptr;
     const Batch& bt = c->bt;
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
-    if (chol) {
-        vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, bt);     // the matrix itself, for the refinement of the solves
-        LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
-    }
-    else      LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
+    if (c->factor_in_head) {}                                                             // factorised beside A.D.A^T
+    else if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
+    else           LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
     if (!c->colsplit) {
@@ -642,7 +822,7 @@ static int run_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const bool graphable = c->use_graph == 1 && !c->profiling && !c->colsplit && o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (!graphable) return enqueue_iteration(c, ip, o);
     for (auto& g : c->graphs)
-        if (g.ip == ip && g.alpha0 == o->alpha0 && g.tol == o->tol) {
+        if (g.ip == ip && g.refine == (int)c->refine_now && g.alpha0 == o->alpha0 && g.tol == o->tol) {
             LP_HIP(hipGraphLaunch(g.exec, c->st));
             return LPIPM_OK;
         }
@@ -656,7 +836,7 @@ static int run_iteration(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     LP_HIP(ei);
-    c->graphs.push_back({ip, o->alpha0, o->tol, exec});
+    c->graphs.push_back({ip, (int)c->refine_now, o->alpha0, o->tol, exec});
     LP_HIP(hipGraphLaunch(exec, c->st));
     return LPIPM_OK;
 }
@@ -684,6 +864,8 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         const char* sp = getenv("LPIPM_SPECULATE");
         c->no_speculate = sp && sp[0] == '0';
     }
+    c->factor_in_head = c->overlap && !c->colsplit && c->use_graph != 1 && o->solver_type == LPIPM_SOLVER_CHOLESKY;
+    c->overlap_sections = 0;
     for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
     c->times = lpipm_phase_times{};
     c->nmarks = 0;
@@ -702,6 +884,8 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         printf("alpha     \trho_p     \trho_d     \trho_g     \trho_mu    \tobj       \n");
         print_row(1.0, *c->status_host);
     }
+    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2)); }
+    c->refine_now = c->refine == 2 || (c->refine == 1 && c->status_host->rho_mu <= refine_below());
     int ip = o->ip ? 1 : 0;
     int ret = LPIPM_ITERATION_LIMIT;
     uint64_t iteration = 0;
@@ -714,6 +898,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
             LP_TRY(run_iteration(c, ip, o));
             LP_HIP(hipStreamSynchronize(st));
             prof_collect(c);
+            prof_collect_overlap(c, c->overlap_sections - 1);
         } else {
             if (!head_out) LP_TRY(enqueue_head(c));
             LP_TRY(enqueue_tail(c, ip, o));
@@ -722,12 +907,14 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
             if (head_out) LP_TRY(enqueue_head(c));
             LP_HIP(hipEventSynchronize(c->ev_status));
             prof_collect(c, marks);
+            prof_collect_overlap(c, c->overlap_sections - (head_out ? 2 : 1));
         }
         ++adat_launches;
         const StatusRec s = *c->status_host;
         // EquationSolverType::build failure (newton_equations.rs:58-63) and the NaN check on p, q
         // (:190-194) both surface as NumericalProblem from get_delta (mod.rs:215)
         if (s.potrf_info != 0 || (s.flags & FLAG_NAN_PQ)) { ret = LPIPM_NUMERICAL_PROBLEM; break; }
+        c->refine_now = c->refine == 2 || (c->refine == 1 && s.rho_mu <= refine_below());   // the next iteration's solves
         ip = 0;                                                    // mod.rs:223
         if (o->disp) print_row(s.alpha, s);
         if (log) {
@@ -760,6 +947,10 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         (void)hipEventElapsedTime(&ms, c->ev_begin, c->ev_end);
         c->times.total_ms = ms;
         c->times.adat_ms = c->tag_ms[T_ADAT]; c->times.potrf_ms = c->tag_ms[T_POTRF];
+        if (c->factor_in_head && c->profiling == 1) {   // T_POTRF spans the whole side-by-side section: what A.D.A^T does not hide
+            c->times.potrf_ms = c->tag_ms[T_POTRF] - c->tag_ms[T_ADAT];
+            if (c->times.potrf_ms < 0.0) c->times.potrf_ms = 0.0;
+        }
         c->times.trsv_ms = c->tag_ms[T_TRSV]; c->times.gemv_ms = c->tag_ms[T_GEMV];
         c->times.vec_ms = c->tag_ms[T_VEC];
         c->times.adat_launches = adat_launches; c->times.iterations = iteration;
@@ -805,6 +996,7 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
     const int B = c->B;
     VecArgs& v = c->va;
     hipStream_t st = c->st;
+    c->factor_in_head = false;
     vec_blind_start(v, st);                                                  // feasible_point.rs:24-31
     LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));                  // feasible_point.rs:32, mod.rs:206
     LP_HIP(hipStreamSynchronize(st));
@@ -812,6 +1004,8 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
     bool head_out = false;
+    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2)); }
+    c->refine_now = c->refine == 2;      // (selective mode) at the starting point mu / mu_0 = 1: no member refines its first iteration
     for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
         if (!head_out) LP_TRY(enqueue_head(c));
         LP_TRY(enqueue_tail(c, ip, o));
@@ -828,6 +1022,11 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
             else if (s.status == ST_UNBOUNDED) ret[i] = LPIPM_UNBOUNDED;     // :233
             if (ret[i] >= 0) { its[i] = iteration; --running; }
         }
+        // the refinement launches of the next iteration are enqueued if ANY running member asks for them; which members
+        // they touch is each member's own device word (k_scalar_indicators), the same decision as when it is solved alone
+        c->refine_now = c->refine == 2;
+        for (int i = 0; i < B && c->refine == 1 && !c->refine_now; ++i)
+            if (ret[i] < 0 && c->status_host[i].rho_mu <= refine_below()) c->refine_now = true;
     }
     for (int i = 0; i < B; ++i)
         if (ret[i] < 0) { ret[i] = LPIPM_ITERATION_LIMIT; its[i] = o->max_iter; }   // mod.rs:237-239

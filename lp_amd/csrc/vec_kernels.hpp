@@ -16,6 +16,11 @@ enum {
 };
 enum { ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_UNBOUNDED = 2, ST_UNFINISHED = 3 };  // indicators.rs:85-90
 enum { FLAG_NAN_PQ = 1 };
+// Selective refinement (LPIPM_REFINE=1, a measurement mode; the default refines every solve): the Cholesky solves of an
+// iteration are refined when mu / mu_0 of the point the normal equations are formed at is at most this.  The decision is
+// the LP's own (device word skip_refine, mirrored by the host from the status record): the same alone and in a batch.
+constexpr double REFINE_BELOW_RHO_MU = 1e-2;
+double refine_below();   // REFINE_BELOW_RHO_MU, or LPIPM_REFINE_BELOW from the environment (measurement knob)
 
 // read back once per iteration (96 bytes)
 struct StatusRec {
@@ -41,8 +46,11 @@ struct VecArgs {
     StatusRec* status;
     int32_t *potrf_info;
     int *flags;
+    int *skip_refine; // set by k_scalar_indicators: 1 = the refinement step of this LP's Cholesky solves is skipped in the next
+                      //   iteration (the LP has finished, or its normal equations are still well conditioned)
     int *done;        // set by k_scalar_indicators when the LP has reached a final status; cleared by k_blind_start
     const int *done_chk;  // what the kernels of the iteration test before doing anything (nullptr: no test)
+    double refine_below;  // threshold of skip_refine (refine_below())
     int bcount;       // lockstep batch: LPs per launch (gridDim.z); every pointer above is LP 0's,
     long long bstride;//   LP z's is bstride bytes * z further
 };

@@ -34,7 +34,8 @@ for k in ("single", "lock"):
     e = err[k]
     if np.isnan(e).all(): continue
     bad = np.where(e > bar)[0]
-    print(f"{k}: iteration mismatches {(its[k] != g['iterations'][:K]).sum()}; |x-x_oracle| median {np.median(e):.2e} max {e.max():.2e}; "
+    mm = np.where(its[k] != g['iterations'][:K])[0]
+    print(f"{k}: iteration mismatches {[(int(s_), int(its[k][s_]), int(g['iterations'][s_]), float(g['floor'][s_])) for s_ in mm]}; |x-x_oracle| median {np.median(e):.2e} max {e.max():.2e}; "
           f"> 1e-6: {(e > 1e-6).sum()}; > max(1e-6,10*floor): {len(bad)} {bad.tolist()}")
     print(f"   err vs planted x*: median {np.median(xerr[k]):.2e}; oracle's own {np.median(g['xstar_err'][:K]):.2e}; "
           f"members where {k} is further from x* than the oracle: {(xerr[k] > g['xstar_err'][:K]).sum()} of {K}")

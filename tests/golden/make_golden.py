@@ -49,14 +49,26 @@ def main():
     todo = PLANTED + (PLANTED_BIG if "--big" in sys.argv else [])
     if "--only-big" in sys.argv:     # python tests/golden/make_golden.py --only-big <seed>   (one process per seed)
         todo = [t for t in PLANTED_BIG if t[0] == int(sys.argv[sys.argv.index("--only-big") + 1])]
+    if "--only-small" in sys.argv:
+        todo = PLANTED
     for seed, m, n in todo:
         A, b, c, xstar = synth.planted_lp(seed, m, n)
         r = oracle.solve(A, b, c)
         assert r["status"] == 0
+        # the oracle's own rounding noise on this LP: the same LP with its columns permuted, solved again (2 times);
+        # floor = largest |dx| among them, inf if a permuted run stops at another iteration (its count is recorded)
+        floor, its_perm = 0.0, []
+        for k in range(2):
+            perm = np.random.default_rng(1000 * (k + 1) + seed).permutation(n)
+            r2 = oracle.solve(np.ascontiguousarray(A[:, perm]), b, np.ascontiguousarray(c[perm]), want_log=False)
+            x2 = np.empty(n)
+            x2[perm] = r2["x_slack"]
+            its_perm.append(r2["iterations"])
+            floor = max(floor, float(np.abs(x2 - r["x_slack"]).max()) if r2["iterations"] == r["iterations"] else float("inf"))
         np.savez_compressed(os.path.join(HERE, f"planted_{m}x{n}_s{seed}.npz"), x_slack=r["x_slack"],
                             fun=r["fun"], iterations=r["iterations"], log=np.array(r["log"]),
-                            xstar_err=np.abs(r["x_slack"] - xstar).max())
-        print(m, n, seed, "iterations", r["iterations"], "max|x - x*|", np.abs(r["x_slack"] - xstar).max())
+                            xstar_err=np.abs(r["x_slack"] - xstar).max(), floor=floor, iterations_permuted=np.array(its_perm))
+        print(m, n, seed, "iterations", r["iterations"], its_perm, "max|x - x*|", np.abs(r["x_slack"] - xstar).max(), "floor", floor)
 
 
 if __name__ == "__main__":

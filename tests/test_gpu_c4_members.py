@@ -64,7 +64,8 @@ def test_c4_members_match_oracle(c4_runs, path):
     floor = g["floor"]
     bar = np.maximum(1e-6, 10.0 * floor)
     err = np.abs(xs[path] - g["x_slack"]).max(axis=1)
-    wrong_it = np.where(its[path] != g["iterations"])[0]
+    # a member whose oracle count changes when only the oracle's summation orders change (floor = inf) may take either
+    wrong_it = np.where((its[path] != g["iterations"]) & ~((its[path] == g["iterations_permuted"]) & ~np.isfinite(floor)))[0]
     over = np.where(err > bar)[0]
     loose = np.where(floor > 1e-7)[0]
     print(f"\n[{path}] |x - x_oracle|: median {np.median(err):.2e}, max {err.max():.2e}; members > 1e-6: "
