@@ -231,6 +231,9 @@ int lpipm_k_qr_solve(lpipm_ctx* ctx, uint64_t m, const double* M, int nrhs, cons
 int lpipm_k_gemv_n(lpipm_ctx* ctx, int nrhs, const double* W, double* Y, int repeats, double* ms_out);
 /* A^T.v (feasible_point.rs:123, newton_equations.rs:223, residual.rs:25): V nrhs x m -> U nrhs x n */
 int lpipm_k_gemv_t(lpipm_ctx* ctx, int nrhs, const double* V, double* U, int repeats, double* ms_out);
+/* residual.rs:23,25 / feasible_point.rs:122-123 in ONE read of A: Aw_out[m] = A.w, ATv_out[n] = A^T.v (w[n], v[m]). */
+int lpipm_k_gemv_dual(lpipm_ctx* ctx, const double* w, const double* v, double* Aw_out, double* ATv_out, int repeats,
+                      double* ms_out);
 /* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64 back to back, operands in registers):
  * tflops_out = achieved TFLOP/s over the whole chip; used to confirm the roofline denominator. */
 int lpipm_k_mfma_f64_probe(lpipm_ctx* ctx, int iters, double* tflops_out, double* ms_out);

@@ -449,6 +449,13 @@ class Context:
         _raise_for(_capi.lib().lpipm_k_gemv_t(self._h, V.shape[0], _p(V), _p(U), repeats, C.byref(ms)))
         return U, ms.value
 
+    def k_gemv_dual(self, w, v, repeats=1):
+        w, v = _f64(w), _f64(v)
+        Aw, ATv = np.empty(self.m), np.empty(self.n)
+        ms = C.c_double(0)
+        _raise_for(_capi.lib().lpipm_k_gemv_dual(self._h, _p(w), _p(v), _p(Aw), _p(ATv), repeats, C.byref(ms)))
+        return Aw, ATv, ms.value
+
     def k_mfma_f64_probe(self, iters=20000):
         tf, ms = C.c_double(0), C.c_double(0)
         _raise_for(_capi.lib().lpipm_k_mfma_f64_probe(self._h, iters, C.byref(tf), C.byref(ms)))

@@ -115,6 +115,68 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemv_dual: A.w AND A^T.v in ONE read of A -- the residual pair of Residuals::calculate (residual.rs:23,25), which is
+// also the r_P, r_D of the next get_delta (feasible_point.rs:122-123).
+//   unit (row block of 128 rows, chunk of CW columns); wave w takes rows w, w+4, ...; a lane holds 2 adjacent columns
+//   per 128-column step:
+//     row part     AxPart[ch][r]  = sum_{c in chunk} A(r,c) w[c]      (wave reduction per row)
+//     column part  Upart[rb][c]   = sum_{r in block} A(r,c) v[r]      (lane accumulators, the 4 waves added in order)
+//   the consumers (k_residuals) add the chunk slabs / the row-block slabs in index order.
+template <int CW>
+__global__ __launch_bounds__(256) void gemv_dual_kernel(const double* __restrict__ A, long long lda, int np,
+                                                        const double* __restrict__ W, const double* __restrict__ V,
+                                                        double* __restrict__ AxPart, long long mp,
+                                                        double* __restrict__ Upart, long long slab, BatchK bk) {
+    if (batch_done(bk)) return;
+    A = batch_ptr(A, bk); W = batch_ptr(W, bk); V = batch_ptr(V, bk); AxPart = batch_ptr(AxPart, bk); Upart = batch_ptr(Upart, bk);
+    constexpr int NS = CW / 128;
+    const int ch = blockIdx.x, rb = blockIdx.y;
+    const int r0 = rb * GEMVT_ROWS, c0 = ch * CW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double vrow[GEMVT_ROWS];
+    __shared__ double csum[4][CW];
+    for (int e = threadIdx.x; e < GEMVT_ROWS; e += 256) vrow[e] = V[r0 + e];
+    d2 wc[NS], cacc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int col = c0 + s * 128 + 2 * lane;
+        wc[s] = col < np ? *(const d2*)(W + col) : (d2){0.0, 0.0};
+        cacc[s] = (d2){0.0, 0.0};
+    }
+    __syncthreads();
+    for (int rr = wave; rr < GEMVT_ROWS; rr += 4) {
+        const double* row = A + (long long)(r0 + rr) * lda + c0 + 2 * lane;
+        const double vr = vrow[rr];
+        double racc = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (c0 + s * 128 + 2 * lane < np) {
+                const d2 a = *(const d2*)(row + s * 128);
+                racc += a[0] * wc[s][0] + a[1] * wc[s][1];
+                cacc[s] += a * vr;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) racc += __shfl_xor(racc, off, 64);
+        if (lane == 0) AxPart[(long long)ch * mp + r0 + rr] = racc;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *(d2*)&csum[wave][s * 128 + 2 * lane] = cacc[s];
+    __syncthreads();
+    for (int e = threadIdx.x; e < CW; e += 256)
+        if (c0 + e < np) Upart[(long long)rb * slab + c0 + e] = ((csum[0][e] + csum[1][e]) + csum[2][e]) + csum[3][e];
+}
+int gemv_dual_chunks(int np) { return np >= 4096 ? (np + 1023) / 1024 : (np + 255) / 256; }
+hipError_t launch_gemv_dual(const double* A, int64_t lda, int mp, int np, const double* W, const double* V, double* AxPart,
+                            double* Upart, int64_t slab, hipStream_t st, const Batch& bt) {
+    if (slab <= 0) slab = np;
+    const dim3 grid(gemv_dual_chunks(np), mp / GEMVT_ROWS, bt.count);
+    if (np >= 4096) hipLaunchKernelGGL(gemv_dual_kernel<1024>, grid, dim3(256), 0, st, A, (long long)lda, np, W, V, AxPart, (long long)mp, Upart, (long long)slab, batch_k(bt));
+    else            hipLaunchKernelGGL(gemv_dual_kernel<256>, grid, dim3(256), 0, st, A, (long long)lda, np, W, V, AxPart, (long long)mp, Upart, (long long)slab, batch_k(bt));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // rho = r0 - M.v for a symmetric M of which only the LOWER triangle is stored (the image A.D.A^T leaves), ONE read
 // of that triangle: a stored element M(r,c), c < r, serves row r (M(r,c).v_c) and, as M(c,r), row c (M(r,c).v_r).
 // This is the residual of the iterative-refinement step that makes the Cholesky solve of the normal equations as

@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
     const double tau = a.S[S_TAU];
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) {
-        const double r = a.b[i] * tau - a.Ax[i];
+        double ax = a.Ax[i];
+        for (int ch = 1; ch < a.ax_chunks; ++ch) ax += a.Ax[(long long)ch * a.mp + i];
+        const double r = a.b[i] * tau - ax;
         a.rP[i] = r;
         acc[0] += r * r;
         acc[1] += a.b[i] * a.y[i];

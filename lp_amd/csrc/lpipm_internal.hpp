@@ -194,6 +194,11 @@ constexpr int GEMVT_ROWS = 128;
 // np: columns processed (multiple of 2); slab: stride between slabs (0 = np)
 hipError_t launch_gemv_t(const double* A, int64_t lda, int mp, int np, int nrhs, const double* V,
                          int64_t ldv, double* Upart, hipStream_t st, int64_t slab = 0, const Batch& bt = Batch{});
+// One read of A for both products of the residual pair: AxPart[ch][i] = sum over column chunk ch of A[i][k] W[k]
+// (gemv_dual_chunks(np) slabs of mp doubles: consumers add them in order) and the row-split slabs of A^T.V as gemv_t.
+int gemv_dual_chunks(int np);
+hipError_t launch_gemv_dual(const double* A, int64_t lda, int mp, int np, const double* W, const double* V, double* AxPart,
+                            double* Upart, int64_t slab, hipStream_t st, const Batch& bt = Batch{});
 // Rho[q] = R0[q] - M.V[q] (q < nrhs) for a symmetric mp x mp M whose LOWER triangle is stored (one read of it);
 // slabs: symv_slab_doubles(mp) doubles of scratch.  The residual of the refinement step of the Cholesky solve.
 size_t symv_slab_doubles(int mp);

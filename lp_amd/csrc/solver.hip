@@ -66,11 +66,13 @@ struct lpipm_ctx {
     std::vector<int> grp_off, grp_nt;    // tile sub-list of every column group (outer panel of the factorisation)
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
-    int refine = -1;             // -1: decide from the environment at first use.  2 (default): every solve of every iteration is
-                                 //   refined; 0: never (LPIPM_REFINE=0); 1: only from mu / mu_0 <= refine_below() on (LPIPM_REFINE=1).
-                                 //   Measured on the 256 C4 members: "never" and every selective threshold (1e-2, 1e-1, 1) leave
-                                 //   some member with a poor step (another member each time: 202 and 217, 217, 89, 160) and one
-                                 //   iteration more than the oracle; "always" leaves none.
+    int refine = -1;             // -1: decide from the environment at first use.  0 (default): plain solves; LPIPM_REFINE=2: every
+                                 //   solve of every iteration refined; =1: only from mu / mu_0 <= refine_below() on.
+                                 //   Built because ~1 % of the C4 members took a poor last step (alpha 0.987 for 0.99995) and
+                                 //   one iteration more than the oracle; measured on all 256 members, no mode removes such
+                                 //   members -- each variant has its own one or two, always among the members whose last
+                                 //   d_tau is ill-determined in fp64 (tests/golden/make_c4_members.py, margin()): the oracle
+                                 //   does the same under a permutation of its columns.  Refinement costs 7-20 % and is off.
     bool refine_now = false;     // the iteration being enqueued refines its solves (host mirror of the LPs' skip_refine words)
     int2* tile_list = nullptr;
     int2* tile_list_grp = nullptr;      // the same tiles grouped by column group (behind tile_list in one allocation)
@@ -388,7 +390,7 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.p = ar.take<double>(np); v.u = ar.take<double>(np); v.dx = ar.take<double>(np); v.dz = ar.take<double>(np);
     v.dxdz = ar.take<double>(np);
     v.rP = ar.take<double>(mp); v.rP2 = ar.take<double>(mp); v.q = ar.take<double>(mp); v.dy = ar.take<double>(mp);
-    v.Ax = ar.take<double>(mp);
+    v.Ax = ar.take<double>(mp * (size_t)gemv_dual_chunks((int)np));
     v.W = ar.take<double>(2 * np); v.R = ar.take<double>(2 * mp);
     c->Y = ar.take<double>(2 * mp);
     c->ATpart = ar.take<double>((size_t)c->nsplit * 2 * np);
@@ -608,7 +610,7 @@ static GemmArgs adat_args(lpipm_ctx* c, const Batch& bt) {
     g.C = c->M; g.ldc = c->mp; g.K = c->npa; g.alpha = 1.0; g.beta = 0.0;
     g.ntiles = c->ntiles; g.tiles_lower = 1; g.ntj = 0; g.tile_list = c->tile_list;
     g.diag_pad_from = (int)c->m; g.ws = c->ws; g.nwg = c->adat_nwg; g.batch = bt; g.sk_claim = c->sk_claim; g.streamk = 1;
-    g.C2 = gemm_streamk_split(c->npa / BK) ? c->M0 : nullptr;
+    g.C2 = (c->refine > 0 && gemm_streamk_split(c->npa / BK)) ? c->M0 : nullptr;    // only the refined solves need M itself
     return g;
 }
 static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
@@ -617,6 +619,7 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     if (e != hipSuccess) return e;
     e = launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
     if (e != hipSuccess) return e;
+    if (c->refine <= 0) return hipSuccess;
     if (g.C2) return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M0, c->mp, c->st, bt);
     vec_copy_lower(c->M, c->M0, c->mp, c->mp, c->st, bt);     // short contraction: one store per tile, copied afterwards
     return hipGetLastError();
@@ -657,7 +660,7 @@ static int enqueue_factor_overlapped(lpipm_ctx* c, const Batch& bt) {
         if (c->ns > J0 * NB) {
             const int r0 = J0 * NB, cnt = (c->ns < J1 * NB ? c->ns : J1 * NB) - r0;
             LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
-            LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M0 + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
+            if (a.C2) LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M0 + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
         }
         if (timed) LP_HIP(hipEventRecord(ev[4 * g + 1], sa));
         if (g > 0) {   // ... minus what the panels before it contribute: C -= L[rows, 0:K) . L[cols, 0:K)^T
@@ -681,13 +684,9 @@ static int enqueue_factor_overlapped(lpipm_ctx* c, const Batch& bt) {
     return LPIPM_OK;
 }
 
-// v = M^-1 r through the Cholesky factor (newton_equations.rs:151-169), with one step of iterative refinement against
-// the matrix itself:  v0 = L^-T L^-1 r;  rho = r - M.v0;  v = v0 + L^-T L^-1 rho.
-// Why: the factor is consumed through explicit inverses of its diagonal super-blocks (kernels_trsv.hip) -- a solve is
-// a handful of parallel mat-vecs instead of mp/128 dependent steps, but its backward error grows with the condition
-// of a super-block, and on the normal equations of the LAST iterations (x/z spanning 1e-9..1e9) that cost ~1 % of the
-// C4 members a visibly wrong direction (alpha 0.987 instead of 0.99995, one more iteration than the reference).  One
-// refinement step brings the solve back to the backward error of the reference's substitution.  R: nrhs x mp, in/out.
+// v = M^-1 r through the Cholesky factor (newton_equations.rs:151-169); optionally (LPIPM_REFINE, see lpipm_ctx::refine)
+// with one step of iterative refinement against the matrix itself:  v0 = L^-T L^-1 r;  rho = r - M.v0 (doubled
+// precision, one read of the lower triangle);  v = v0 + L^-T L^-1 rho.  R: nrhs x mp, in/out.
 static int chol_solve_refined(lpipm_ctx* c, int nrhs, double* R, const Batch& bt) {
     hipStream_t st = c->st;
     if (!c->refine_now) { LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt)); return LPIPM_OK; }
@@ -706,9 +705,18 @@ static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol)
     VecArgs& v = c->va;
     // A.x and A^T.y at the current point (residual.rs:23,25)
     XRank xr{xrank_fn, c};
-    LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax, c->bt));
-    LP_TRY(ctx_allreduce(c, v.Ax, c->m, 0));          // n-split: A.x = sum over ranks of A_g.x_g
-    LP_HIP(ctx_gemv_t(c, 1, v.y, c->bt));
+    if (!(c->colsplit && c->world > 1)) {       // both products in one read of A
+        ++c->gemv_passes;
+        v.ax_chunks = gemv_dual_chunks(c->npa);
+        LP_HIP(launch_gemv_dual(c->A, c->npa, c->mp, c->npa, v.x, v.y, v.Ax, c->ATpart, c->np, c->st, c->bt));
+        LP_HIP(launch_slack_n(c->ns, c->nx, 1, v.x, c->np, v.Ax, c->mp, c->st, c->bt));          // into chunk slab 0
+        LP_HIP(launch_slack_t(c->ns, c->nx, 1, c->nsplit, v.y, c->mp, c->ATpart, c->np, c->st, c->bt));
+    } else {
+        v.ax_chunks = 1;
+        LP_HIP(ctx_gemv_n(c, 1, v.x, nullptr, nullptr, v.Ax, c->bt));
+        LP_TRY(ctx_allreduce(c, v.Ax, c->m, 0));          // n-split: A.x = sum over ranks of A_g.x_g
+        LP_HIP(ctx_gemv_t(c, 1, v.y, c->bt));
+    }
     prof_mark(c, T_GEMV);
     LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->st, c->colsplit ? &xr : nullptr));
     LP_HIP(hipGetLastError());
@@ -749,7 +757,7 @@ static int enqueue_head(lpipm_ctx* c) {
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
         LP_TRY(ctx_allreduce(c, c->mpack, c->mpack_count, 0));
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 1, st);
-        vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, c->bt_head);         // the summed matrix, for the refined solves
+        if (c->refine > 0) vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, c->bt_head);   // the summed matrix, for the refined solves
     }
     prof_mark(c, T_ADAT, true);
     return LPIPM_OK;
@@ -884,7 +892,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         printf("alpha     \trho_p     \trho_d     \trho_g     \trho_mu    \tobj       \n");
         print_row(1.0, *c->status_host);
     }
-    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2)); }
+    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     c->refine_now = c->refine == 2 || (c->refine == 1 && c->status_host->rho_mu <= refine_below());
     int ip = o->ip ? 1 : 0;
     int ret = LPIPM_ITERATION_LIMIT;
@@ -1004,7 +1012,7 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
     bool head_out = false;
-    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 2 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2)); }
+    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     c->refine_now = c->refine == 2;      // (selective mode) at the starting point mu / mu_0 = 1: no member refines its first iteration
     for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
         if (!head_out) LP_TRY(enqueue_head(c));
@@ -1500,6 +1508,33 @@ extern "C" int lpipm_k_gemv_t(lpipm_ctx* c, int nrhs, const double* V, double* U
     LP_HIP(hipMemcpy2DAsync(U, c->n * sizeof(double), c->va.W, (size_t)c->np * sizeof(double), c->n * sizeof(double),
                             nrhs, hipMemcpyDeviceToHost, c->st));
     LP_HIP(hipStreamSynchronize(c->st));
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_k_gemv_dual(lpipm_ctx* c, const double* w, const double* v, double* Aw_out, double* ATv_out, int repeats,
+                                 double* ms_out) {
+    if (!c || !w || !v || !Aw_out || !ATv_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    LP_HIP(hipSetDevice(c->device));
+    VecArgs& va = c->va;
+    LP_HIP(hipMemsetAsync(va.W, 0, (size_t)c->np * sizeof(double), c->st));
+    LP_HIP(hipMemsetAsync(va.R, 0, (size_t)c->mp * sizeof(double), c->st));
+    LP_HIP(hipMemcpyAsync(va.W, w, c->n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    LP_HIP(hipMemcpyAsync(va.R, v, c->m * sizeof(double), hipMemcpyHostToDevice, c->st));
+    const int nch = gemv_dual_chunks(c->npa);
+    LP_TRY(timed_repeats(c, repeats, ms_out, [&]() -> int {
+        LP_HIP(launch_gemv_dual(c->A, c->npa, c->mp, c->npa, va.W, va.R, va.Ax, c->ATpart, c->np, c->st));
+        LP_HIP(launch_slack_n(c->ns, c->nx, 1, va.W, c->np, va.Ax, c->mp, c->st));
+        LP_HIP(launch_slack_t(c->ns, c->nx, 1, c->nsplit, va.R, c->mp, c->ATpart, c->np, c->st));
+        return LPIPM_OK;
+    }));
+    // the consumers' folds, on the host: chunk slabs of A.w, row-block slabs of A^T.v, in index order
+    std::vector<double> ax((size_t)nch * c->mp), at((size_t)c->nsplit * c->np);
+    LP_HIP(hipMemcpyAsync(ax.data(), va.Ax, ax.size() * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipMemcpyAsync(at.data(), c->ATpart, at.size() * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    LP_HIP(hipStreamSynchronize(c->st));
+    for (uint64_t i = 0; i < c->m; ++i) { double s = 0.0; for (int ch = 0; ch < nch; ++ch) s += ax[(size_t)ch * c->mp + i]; Aw_out[i] = s; }
+    for (uint64_t j = 0; j < c->n; ++j) { double s = 0.0; for (int sp = 0; sp < c->nsplit; ++sp) s += at[(size_t)sp * c->np + j]; ATv_out[j] = s; }
     return LPIPM_OK;
 }
 

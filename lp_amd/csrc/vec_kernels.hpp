@@ -50,6 +50,7 @@ struct VecArgs {
                       //   iteration (the LP has finished, or its normal equations are still well conditioned)
     int *done;        // set by k_scalar_indicators when the LP has reached a final status; cleared by k_blind_start
     const int *done_chk;  // what the kernels of the iteration test before doing anything (nullptr: no test)
+    int ax_chunks;    // Ax holds this many slabs of mp doubles whose sum is A.x (1: a plain gemv_n result)
     double refine_below;  // threshold of skip_refine (refine_below())
     int bcount;       // lockstep batch: LPs per launch (gridDim.z); every pointer above is LP 0's,
     long long bstride;//   LP z's is bstride bytes * z further

@@ -11,7 +11,11 @@ and the largest |x - x_permuted|_inf recorded (inf if a permuted run stops at an
 The reference itself cannot run here (Rust, no toolchain): these vectors come from the restatement, which the
 reference's known answers pin end to end (tests/test_oracle_golden.py).
 
+`dtau_margin` (see margin() below) marks the members whose LAST step is ill-determined in fp64 whatever the
+implementation; the parity tests let those take another number of iterations than the oracle did.
+
 Run from the repo root:  python tests/golden/make_c4_members.py [--seeds 256] [--procs 8]
+                         OPENBLAS_NUM_THREADS=1 python tests/golden/make_c4_members.py --margins-only
 """
 import argparse
 import os
@@ -45,11 +49,44 @@ def one(seed):
             floor, max(its2, key=lambda v: abs(v - r["iterations"])), alphas)
 
 
+def margin(seed):
+    """How well determined the LAST iteration's direction is: Delta::compute (delta.rs:29-32) divides by
+    kappa/tau + (-c.p + b.q), and near the optimum c.p and b.q agree to many digits.  margin = |that denominator| /
+    max(|c.p|, |b.q|) at the oracle's last iterate (numpy transcription of the oracle, traced).  A Cholesky solve of
+    these normal equations (cond ~1e9) delivers q to ~1e-8 relative in ANY fp64 implementation, so below ~1e-6 the
+    denominator -- hence d_tau, hence the whole last step -- has one or two significant digits: whether that step is
+    clean (alpha = 0.99995) or poor (and the solver needs more iterations) is decided by rounding."""
+    import scipy.linalg as sla
+    from lp_amd import synth
+    from oracle import oracle_np
+    A, b, c, _ = synth.planted_lp(seed, M, N)
+    tr = []
+    oracle_np.solve(A, b, c, trace=tr)
+    x, y, z, tau, kappa = tr[-1]
+    d = x / z
+    cf = sla.cho_factor(A @ (d[:, None] * A.T), lower=True)
+    q = sla.cho_solve(cf, b + A @ (d * c))
+    p = d * (A.T @ q - c)
+    cp, bq = c @ p, b @ q
+    return abs(kappa / tau - cp + bq) / max(abs(cp), abs(bq))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=256)
     ap.add_argument("--procs", type=int, default=8)
+    ap.add_argument("--margins-only", action="store_true", help="add dtau_margin to the existing file")
     a = ap.parse_args()
+    if a.margins_only:
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+        path = os.path.join(HERE, "c4_members.npz")
+        g = dict(np.load(path))
+        with Pool(a.procs) as p:
+            g["dtau_margin"] = np.array(p.map(margin, [int(s) for s in g["seeds"]], chunksize=1))
+        np.savez_compressed(path, **g)
+        print("margins: min %.1e median %.1e; below 2e-6: %d" % (g["dtau_margin"].min(), np.median(g["dtau_margin"]),
+                                                                   int((g["dtau_margin"] < 2e-6).sum())))
+        return
     with Pool(a.procs) as p:
         rows = p.map(one, range(a.seeds), chunksize=1)
     rows.sort(key=lambda r: r[0])

@@ -158,3 +158,21 @@ def test_symv_residual_reads_only_the_lower_triangle(ctx, m, nrhs):
     got = ctx.k_symv_residual(L, V, R0)
     ref = R0 - V @ S
     assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("m,n", [(3, 4), (100, 333), (512, 1024), (130, 5000), (1024, 2048)])
+def test_gemv_dual_one_read_of_A(ctx, m, n):
+    """A.w and A^T.v from one pass over A (the residual pair, residual.rs:23,25) against the oracle's two GEMVs."""
+    from lp_amd import synth
+    from oracle import capi as oracle
+    A, b, c, _ = synth.planted_lp(1, m, n)
+    ctx.upload_arrays(A, b, c)
+    rng = np.random.default_rng(m * n)
+    w, v = rng.standard_normal(n), rng.standard_normal(m)
+    Aw, ATv, _ = ctx.k_gemv_dual(w, v)
+    p = lambda a: a.ctypes.data_as(oracle.C.POINTER(oracle.C.c_double))
+    rn, rt = np.empty(m), np.empty(n)
+    oracle.lib().oracle_gemv_n(m, n, p(A), p(w), p(rn))
+    oracle.lib().oracle_gemv_t(m, n, p(A), p(v), p(rt))
+    assert np.abs(Aw - rn).max() <= 1e-12 * max(1.0, np.abs(rn).max()) * np.sqrt(n)
+    assert np.abs(ATv - rt).max() <= 1e-12 * max(1.0, np.abs(rt).max()) * np.sqrt(m)
