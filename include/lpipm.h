@@ -231,6 +231,14 @@ int lpipm_k_qr_solve(lpipm_ctx* ctx, uint64_t m, const double* M, int nrhs, cons
 int lpipm_k_gemv_n(lpipm_ctx* ctx, int nrhs, const double* W, double* Y, int repeats, double* ms_out);
 /* A^T.v (feasible_point.rs:123, newton_equations.rs:223, residual.rs:25): V nrhs x m -> U nrhs x n */
 int lpipm_k_gemv_t(lpipm_ctx* ctx, int nrhs, const double* V, double* U, int repeats, double* ms_out);
+/* One loop body of solve_normal_form (mod.rs:215-222) on the uploaded problem from a GIVEN iterate: get_delta
+ * (feasible_point.rs:110-152: residuals, normal equations + factor, Rhat::predictor / corrector, Delta::compute twice,
+ * update_gamma), the step length (mod.rs:216-221, feasible_point.rs:53-72) and do_step (:76-106).
+ * In/out: x[n], y[m], z[n], *tau, *kappa.  Out: the corrector's direction d_x[n], d_y[m], d_z[n],
+ * d_tk = {d_tau, d_kappa}, *alpha, *info (pivot failure as lpipm_k_potrf).  Differential tests of the vector stage. */
+int lpipm_k_iteration(lpipm_ctx* ctx, const lpipm_opts* opts, int ip, double* x, double* y, double* z, double* tau,
+                      double* kappa, double* d_x, double* d_y, double* d_z, double* d_tk, double* alpha_out,
+                      int32_t* info_out);
 /* residual.rs:23,25 / feasible_point.rs:122-123 in ONE read of A: Aw_out[m] = A.w, ATv_out[n] = A^T.v (w[n], v[m]). */
 int lpipm_k_gemv_dual(lpipm_ctx* ctx, const double* w, const double* v, double* Aw_out, double* ATv_out, int repeats,
                       double* ms_out);

@@ -449,6 +449,18 @@ class Context:
         _raise_for(_capi.lib().lpipm_k_gemv_t(self._h, V.shape[0], _p(V), _p(U), repeats, C.byref(ms)))
         return U, ms.value
 
+    def k_iteration(self, opts, x, y, z, tau, kappa, ip=False):
+        """One loop body of solve_normal_form from the given iterate (lpipm_k_iteration).
+        -> dict(x, y, z, tau, kappa, d_x, d_y, d_z, d_tau, d_kappa, alpha, info)"""
+        x, y, z = _f64(x).copy(), _f64(y).copy(), _f64(z).copy()
+        tk = np.array([float(tau), float(kappa)])
+        dx, dy, dz, dtk, al = np.empty(self.n), np.empty(self.m), np.empty(self.n), np.empty(2), np.empty(1)
+        info = C.c_int32(0)
+        _raise_for(_capi.lib().lpipm_k_iteration(self._h, C.byref(opts), int(bool(ip)), _p(x), _p(y), _p(z), _p(tk[0:1]),
+                                                 _p(tk[1:2]), _p(dx), _p(dy), _p(dz), _p(dtk), _p(al), C.byref(info)))
+        return dict(x=x, y=y, z=z, tau=float(tk[0]), kappa=float(tk[1]), d_x=dx, d_y=dy, d_z=dz, d_tau=float(dtk[0]),
+                    d_kappa=float(dtk[1]), alpha=float(al[0]), info=info.value)
+
     def k_gemv_dual(self, w, v, repeats=1):
         w, v = _f64(w), _f64(v)
         Aw, ATv = np.empty(self.m), np.empty(self.n)

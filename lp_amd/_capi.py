@@ -66,6 +66,8 @@ SYMBOLS = {
     "lpipm_k_qr_solve": (C.c_int, [_vp, _u64, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_int32), _dp]),
     "lpipm_k_gemv_n": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
     "lpipm_k_gemv_t": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
+    "lpipm_k_iteration": (C.c_int, [_vp, C.POINTER(Opts), C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                    C.POINTER(C.c_int32)]),
     "lpipm_k_gemv_dual": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "lpipm_k_mfma_f64_probe": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "lpipm_synth_planted_lp": (C.c_int, [_u64, _u64, _u64, _dp, _dp, _dp, _dp]),

@@ -1511,6 +1511,45 @@ extern "C" int lpipm_k_gemv_t(lpipm_ctx* c, int nrhs, const double* V, double* U
     return LPIPM_OK;
 }
 
+// One loop body of solve_normal_form (mod.rs:215-222) on the uploaded problem from a GIVEN iterate: what the loop does
+// between two status read-backs -- residuals at the point (feasible_point.rs:122-125), normal equations, factor,
+// predictor, corrector, step length, step.  For the differential tests of the vector stage (rhat.rs, delta.rs,
+// feasible_point.rs:53-106) on arbitrary iterates, including ip = 1.
+extern "C" int lpipm_k_iteration(lpipm_ctx* c, const lpipm_opts* o, int ip, double* x, double* y, double* z, double* tau,
+                                 double* kappa, double* d_x, double* d_y, double* d_z, double* d_tk, double* alpha_out,
+                                 int32_t* info_out) {
+    if (!c || !o || !x || !y || !z || !tau || !kappa || !d_x || !d_y || !d_z || !d_tk || !alpha_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
+    if (c->B != 1 || c->colsplit) return LPIPM_ERR_UNSUPPORTED;
+    LP_HIP(hipSetDevice(c->device));
+    VecArgs& v = c->va;
+    hipStream_t st = c->st;
+    if (c->refine < 0) c->refine = 0;
+    c->refine_now = c->refine == 2;
+    c->factor_in_head = false;
+    vec_blind_start(v, st);                                   // clears done / flags; the iterate is overwritten next
+    LP_HIP(hipMemcpyAsync(v.x, x, c->n * sizeof(double), hipMemcpyHostToDevice, st));
+    LP_HIP(hipMemcpyAsync(v.y, y, c->m * sizeof(double), hipMemcpyHostToDevice, st));
+    LP_HIP(hipMemcpyAsync(v.z, z, c->n * sizeof(double), hipMemcpyHostToDevice, st));
+    const double tk[2] = {*tau, *kappa};
+    LP_HIP(hipMemcpyAsync(v.S + S_TAU, &tk[0], sizeof(double), hipMemcpyHostToDevice, st));
+    LP_HIP(hipMemcpyAsync(v.S + S_KAPPA, &tk[1], sizeof(double), hipMemcpyHostToDevice, st));
+    LP_TRY(enqueue_residuals(c, 1, ip ? 1 : 0, o->tol));      // r_P, r_D, r_G, mu at the point
+    LP_TRY(enqueue_iteration(c, ip ? 1 : 0, o));
+    double sc[S_COUNT];
+    LP_HIP(hipMemcpyAsync(sc, v.S, sizeof(sc), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(x, v.x, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(y, v.y, c->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(z, v.z, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(d_x, v.dx, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(d_y, v.dy, c->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipMemcpyAsync(d_z, v.dz, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LP_HIP(hipStreamSynchronize(st));
+    *tau = sc[S_TAU]; *kappa = sc[S_KAPPA]; d_tk[0] = sc[S_DTAU]; d_tk[1] = sc[S_DKAPPA]; *alpha_out = sc[S_ALPHA];
+    if (info_out) *info_out = c->status_host->potrf_info;
+    return LPIPM_OK;
+}
+
 extern "C" int lpipm_k_gemv_dual(lpipm_ctx* c, const double* w, const double* v, double* Aw_out, double* ATv_out, int repeats,
                                  double* ms_out) {
     if (!c || !w || !v || !Aw_out || !ATv_out) return LPIPM_ERR_BAD_ARGUMENT;

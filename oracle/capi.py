@@ -50,6 +50,8 @@ def lib():
         L.oracle_ipm_solve.argtypes = [u64, u64, dp, dp, dp, C.c_double, C.POINTER(Opts), dp, dp,
                                        C.POINTER(u64), C.POINTER(IterRow), C.POINTER(Timing)]
         L.oracle_ipm_solve.restype = C.c_int
+        L.oracle_iteration.argtypes = [u64, u64, dp, dp, dp, C.c_int, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.oracle_iteration.restype = C.c_int
         L.oracle_adat.argtypes = [u64, u64, dp, dp, dp]
         L.oracle_adat.restype = None
         L.oracle_cholesky.argtypes = [u64, dp]
@@ -159,3 +161,17 @@ def gemv_t(A, v):
     u = np.empty(A.shape[1])
     lib().oracle_gemv_t(A.shape[0], A.shape[1], _p(A), _p(v), _p(u))
     return u
+
+
+def iteration(A, b, c, x, y, z, tau, kappa, ip=False, alpha0=0.99995, solver_type=0):
+    """One loop body of solve_normal_form from the given iterate (oracle_iteration).
+    -> dict(status, x, y, z, tau, kappa, d_x, d_y, d_z, d_tau, d_kappa, alpha)"""
+    A, b, c = _f64(A), _f64(b), _f64(c)
+    m, n = A.shape
+    x, y, z = _f64(x).copy(), _f64(y).copy(), _f64(z).copy()
+    tk = np.array([float(tau), float(kappa)])
+    dx, dy, dz, dtk, al = np.empty(n), np.empty(m), np.empty(n), np.empty(2), np.empty(1)
+    rc = lib().oracle_iteration(m, n, _p(A), _p(b), _p(c), int(solver_type), int(bool(ip)), float(alpha0), _p(x), _p(y), _p(z),
+                                _p(tk[0:1]), _p(tk[1:2]), _p(dx), _p(dy), _p(dz), _p(dtk), _p(al))
+    return dict(status=rc, x=x, y=y, z=z, tau=float(tk[0]), kappa=float(tk[1]), d_x=dx, d_y=dy, d_z=dz,
+                d_tau=float(dtk[0]), d_kappa=float(dtk[1]), alpha=float(al[0]))

@@ -372,6 +372,30 @@ static void do_step(point_t* pt, const delta_t* D, double alpha, int ip, uint64_
     }
 }
 
+/* ONE pass of the loop body of solve_normal_form (mod.rs:215-222) from a GIVEN iterate: get_delta
+ * (feasible_point.rs:110-152), the step length (mod.rs:216-221), do_step (feasible_point.rs:76-106).  For the
+ * differential tests of the device's vector stage (rhat.rs, delta.rs, the ratio test, the step) on arbitrary
+ * iterates -- including ip = 1 and directions with zero / negative entries -- not only along trajectories.
+ * In/out: x[n], y[m], z[n], *tau, *kappa.  Out: d_x[n], d_y[m], d_z[n], d_tk[2] = {d_tau, d_kappa}, *alpha. */
+int oracle_iteration(uint64_t m, uint64_t n, const double* A, const double* b, const double* c, int solver_type,
+                     int ip, double alpha0, double* x, double* y, double* z, double* tau, double* kappa,
+                     double* d_x, double* d_y, double* d_z, double* d_tk, double* alpha_out) {
+    problem_t P = {m, n, A, b, c, 0.0, NULL};
+    point_t pt;
+    pt.x = x; pt.y = y; pt.z = z; pt.tau = *tau; pt.kappa = *kappa;
+    memset(&pt.initial_residuals, 0, sizeof(pt.initial_residuals));
+    delta_t D;
+    int rc = get_delta(&pt, &P, solver_type, ip, &D);
+    if (rc) return rc;
+    const double alpha = ip ? 1.0 : get_step_size(&pt, &D, n, alpha0);
+    memcpy(d_x, D.d_x, sizeof(double) * n); memcpy(d_y, D.d_y, sizeof(double) * m); memcpy(d_z, D.d_z, sizeof(double) * n);
+    d_tk[0] = D.d_tau; d_tk[1] = D.d_kappa;
+    do_step(&pt, &D, alpha, ip, m, n);
+    *tau = pt.tau; *kappa = pt.kappa; *alpha_out = alpha;
+    delta_free(&D);
+    return ORACLE_OK;
+}
+
 /* InteriorPoint::solve_normal_form + solve, interior_point/mod.rs:199-240, :161-168 */
 int oracle_ipm_solve(uint64_t m, uint64_t n, const double* A, const double* b, const double* c,
                      double c0, const oracle_opts* opts, double* x_slack_out, double* fun_out,

@@ -61,6 +61,11 @@ int oracle_ipm_solve(uint64_t m, uint64_t n, const double* A, const double* b, c
                      double c0, const oracle_opts* opts, double* x_slack_out, double* fun_out,
                      uint64_t* iterations_out, oracle_iter_row* log, oracle_timing* timing);
 
+/* one loop body of solve_normal_form from a given iterate (see oracle_ipm.c) */
+int oracle_iteration(uint64_t m, uint64_t n, const double* A, const double* b, const double* c, int solver_type,
+                     int ip, double alpha0, double* x, double* y, double* z, double* tau, double* kappa,
+                     double* d_x, double* d_y, double* d_z, double* d_tk, double* alpha_out);
+
 /* kernel-granularity restatements used by the per-kernel differential tests */
 /* newton_equations.rs:54-57: M = A . (Dinv[:,None] * A^T), full square, n x m temporary */
 void oracle_adat(uint64_t m, uint64_t n, const double* A, const double* dinv, double* M);
