@@ -160,6 +160,11 @@ int lpipm_solve_batch(lpipm_ctx* ctx, uint64_t count, const uint64_t* m, const u
  *   op 0 = sum, 1 = min; the stream has been drained before the call; return 0 when the result is in place. */
 typedef int (*lpipm_allreduce_fn)(void* user, void* dev_ptr, uint64_t count, int op, void* stream);
 int lpipm_set_collective(lpipm_ctx* ctx, int rank, int world, lpipm_allreduce_fn fn, void* user);
+/* on = 1: the library no longer drains its stream before calling fn; fn must ENQUEUE the reduction on the stream it
+ * is handed (RCCL: ncclAllReduce(ptr, ptr, count, ncclDouble, op, comm, (hipStream_t)stream)) and may return at once --
+ * stream order makes the result visible to the kernels that follow, and nothing on the host waits (the one
+ * status read-back per iteration excepted).  on = 0 (default): the drained contract described above. */
+int lpipm_set_collective_on_stream(lpipm_ctx* ctx, int on);
 /* Upload this rank's column block; afterwards lpipm_solve / lpipm_solve_device run the n-split algorithm and
  * return this rank's slice of x / tau (n_local doubles); fun, iterations and the log are global. */
 int lpipm_upload_nsplit(lpipm_ctx* ctx, uint64_t m, uint64_t n_total, uint64_t n_local, const double* A_local,

@@ -266,6 +266,7 @@ class Context:
         self._collective = collective
         cfn = C.cast(collective.cfn, C.c_void_p) if collective is not None else None
         _raise_for(_capi.lib().lpipm_set_collective(self._h, int(rank), int(world), cfn, None))
+        _raise_for(_capi.lib().lpipm_set_collective_on_stream(self._h, int(bool(getattr(collective, "on_stream", False)))))
         return self
 
     def upload_column_block(self, A_local, b, c_local, n_total: int, c0=0.0):

@@ -49,6 +49,7 @@ SYMBOLS = {
     "lpipm_solve_batch": (C.c_int, [_vp, _u64, C.POINTER(_u64), C.POINTER(_u64), _dpp, _dpp, _dpp, _dp,
                                     C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),
     "lpipm_set_collective": (C.c_int, [_vp, C.c_int, C.c_int, C.c_void_p, _vp]),
+    "lpipm_set_collective_on_stream": (C.c_int, [_vp, C.c_int]),
     "lpipm_upload_nsplit": (C.c_int, [_vp, _u64, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double]),
     "lpipm_upload_lockstep": (C.c_int, [_vp, _u64, _u64, _u64, _dpp, _dpp, _dpp, _dp]),
     "lpipm_solve_lockstep": (C.c_int, [_vp, C.POINTER(Opts), _dpp, _dp, C.POINTER(_u64), C.POINTER(C.c_int32)]),

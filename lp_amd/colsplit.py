@@ -36,22 +36,39 @@ class _DevPtr:
 
 
 class TorchCollective:
-    """lpipm_allreduce_fn over a torch.distributed process group."""
+    """lpipm_allreduce_fn over a torch.distributed process group.
 
-    def __init__(self, device: int, group=None):
+    on_stream (default: True for the "nccl" backend = RCCL): the library does not drain its stream before calling
+    (lpipm_set_collective_on_stream); the all-reduce is issued with the SOLVER's stream as torch's current stream, so
+    RCCL orders it behind the kernels that produced the operand and the kernels that follow wait for it on the device
+    -- the host never blocks.  Otherwise (gloo: the copy through the host is synchronous anyway) the drained contract."""
+
+    def __init__(self, device: int, group=None, on_stream=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group, self.device = torch, dist, group, int(device)
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.on_stream = (backend == "nccl") if on_stream is None else bool(on_stream)
         self.calls = 0
         self.bytes = 0
         self.error = None
         self.cfn = _capi.ALLREDUCE_FN(self._call)     # keep the thunk alive as long as the ctx uses it
 
-    def _call(self, _user, ptr, count, op, _stream):
+    def _call(self, _user, ptr, count, op, stream):
         try:
             torch, dist = self.torch, self.dist
             t = torch.as_tensor(_DevPtr(ptr, count), device=torch.device("cuda", self.device))
-            dist.all_reduce(t, op=dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.SUM, group=self.group)
+            rop = dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.SUM
+            if self.on_stream:
+                ext = torch.cuda.ExternalStream(int(stream), device=torch.device("cuda", self.device))
+                if dist.get_backend(self.group) != "nccl":
+                    ext.synchronize()                              # a host-staged backend reads the operand now
+                with torch.cuda.stream(ext):
+                    dist.all_reduce(t, op=rop, group=self.group)   # RCCL: enqueued behind / ahead of the solver's kernels
+                self.calls += 1
+                self.bytes += 8 * int(count)
+                return 0
+            dist.all_reduce(t, op=rop, group=self.group)
             torch.cuda.current_stream(self.device).synchronize()   # result in place before the library resumes
             self.calls += 1
             self.bytes += 8 * int(count)
@@ -61,8 +78,16 @@ class TorchCollective:
             return 1
 
 
+def check_split(n: int, world: int, align: int = 128):
+    """Every rank needs at least one column group: with fewer groups than ranks some ranks would hold nothing, refuse
+    their upload, and leave the others waiting in the first all-reduce.  Raises the same error on every rank."""
+    groups = -(-int(n) // align)
+    if world > groups:
+        raise ValueError(f"cannot split {n} columns ({groups} groups of {align}) over {world} ranks: use at most {groups}")
+
+
 def solve_column_split(A_local, b, c_local, n_total: int, c0: float = 0.0, opts=None, ctx=None, group=None,
-                       want_log: bool = False):
+                       want_log: bool = False, on_stream=None):
     """Solve min c.x s.t. A x = b, x >= 0 with this rank holding the column block (A_local, c_local).
     Every rank must call this with the same b / n_total / opts.  Returns
     (status, x_local, fun, iterations, log rows, collective) -- x_local is this rank's slice of x / tau."""
@@ -72,9 +97,10 @@ def solve_column_split(A_local, b, c_local, n_total: int, c0: float = 0.0, opts=
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    check_split(n_total, world)                       # the same verdict on every rank, before anything is uploaded
     ctx = ctx or lp_amd.Context(torch.cuda.current_device())
     opts = opts or lp_amd.InteriorPoint.default().opts()
-    coll = TorchCollective(ctx.device, group)
+    coll = TorchCollective(ctx.device, group, on_stream=on_stream)
     ctx.set_collective(rank, world, coll)
     ctx.upload_column_block(A_local, b, c_local, n_total, c0)
     rc, x, fun, it, rows = ctx.solve_raw(opts, want_log=want_log)

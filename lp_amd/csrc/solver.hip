@@ -110,6 +110,7 @@ struct lpipm_ctx {
     int rank = 0, world = 1;
     lpipm_allreduce_fn coll = nullptr;
     void* coll_user = nullptr;
+    bool coll_on_stream = false;  // the callback enqueues the reduction on the ctx's stream itself (no drain before the call)
     double* gs = nullptr;        // 8 doubles: sums / minima that must be reduced across ranks
     double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
     size_t mpack_count = 0;
@@ -120,12 +121,15 @@ static void drop_graphs(lpipm_ctx* c) {
     c->graphs.clear();
 }
 
-// Cross-rank reduction of `count` doubles at a device pointer, ordered after everything enqueued on the
-// ctx's stream so far (the stream is drained first; the callee returns when the result is in place).
+// Cross-rank reduction of `count` doubles at a device pointer, ordered after everything enqueued on the ctx's stream
+// so far.  Default contract: the stream is drained first and the callee returns when the result is in place.
+// lpipm_set_collective_on_stream(ctx, 1): nothing is drained -- the callee enqueues the reduction ON the stream it is
+// given (ncclAllReduce(..., stream)) and returns at once; stream order does the rest, and the M panels' reduction
+// overlaps whatever the host enqueues next.
 static int ctx_allreduce(lpipm_ctx* c, double* ptr, uint64_t count, int op) {
     if (!c->colsplit || c->world <= 1) return LPIPM_OK;
     if (!c->coll) return LPIPM_ERR_BAD_ARGUMENT;
-    LP_HIP(hipStreamSynchronize(c->st));
+    if (!c->coll_on_stream) LP_HIP(hipStreamSynchronize(c->st));
     if (c->coll(c->coll_user, ptr, count, op, (void*)c->st) != 0) {
         g_err_detail = "the all-reduce callback of lpipm_set_collective reported a failure";
         return LPIPM_ERR_HIP;
@@ -1254,6 +1258,12 @@ extern "C" int lpipm_set_batch_concurrency(lpipm_ctx* c, int nworkers) {
 extern "C" int lpipm_set_collective(lpipm_ctx* c, int rank, int world, lpipm_allreduce_fn fn, void* user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) return LPIPM_ERR_BAD_ARGUMENT;
     c->rank = rank; c->world = world; c->coll = fn; c->coll_user = user;
+    return LPIPM_OK;
+}
+
+extern "C" int lpipm_set_collective_on_stream(lpipm_ctx* c, int on) {
+    if (!c) return LPIPM_ERR_BAD_ARGUMENT;
+    c->coll_on_stream = on != 0;
     return LPIPM_OK;
 }
 

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--one-gpu", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--golden", default=None, help="committed oracle vector (tests/golden/*.npz) to compare the gathered x with")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
@@ -37,14 +39,15 @@ def main():
     import torch.distributed as dist
     import lp_amd
     from lp_amd import synth
-    from lp_amd.colsplit import TorchCollective, column_range
+    from lp_amd.colsplit import TorchCollective, check_split, column_range
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         kw = {"device_id": torch.device("cuda", local_rank)} if args.backend == "nccl" else {}
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
     m, n = args.rows, args.cols
-    A, b, c, xstar = synth.planted_lp(0, m, n)               # same LP on every rank; keep only this rank's columns
+    check_split(n, world)
+    A, b, c, xstar = synth.planted_lp(args.seed, m, n)               # same LP on every rank; keep only this rank's columns
     cols = column_range(n, world, rank)
     A_loc = np.ascontiguousarray(A[:, cols.start:cols.stop])
     c_loc = c[cols.start:cols.stop].copy()
@@ -74,10 +77,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     err = float(np.abs(x - xstar[cols.start:cols.stop]).max())
+    gold_err = None
+    if args.golden:
+        g = np.load(args.golden)
+        gold_err = float(np.abs(x - g["x_slack"][cols.start:cols.stop]).max())
+        if its != int(g["iterations"]):
+            gold_err = float("inf")
     if world > 1:
-        t = torch.tensor([dt, err], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([dt, err, gold_err if gold_err is not None else 0.0], dtype=torch.float64,
+                         device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, err = float(t[0]), float(t[1])
+        if gold_err is not None:
+            gold_err = float(t[2])
     if rank == 0:
         print(json.dumps({
             "metric": "IPM iterations/sec, one dense fp64 LP column-split over ranks", "value": iters / dt,
@@ -86,6 +98,7 @@ def main():
             "config": {"workload": f"C5: one planted dense LP m={m} n={n}, columns split over {world} rank(s), "
                                    f"backend {args.backend if world > 1 else 'none'}",
                        "iterations_per_solve": iters / args.steps, "max_abs_err_vs_planted_optimum": err,
+                       "max_abs_err_vs_golden": gold_err, "collective": "on-stream" if coll.on_stream else "drained",
                        "allreduce_calls_per_iteration": coll.calls / max(iters, 1),
                        "allreduce_MB_per_iteration": coll.bytes / max(iters, 1) / 1e6}}), flush=True)
     if world > 1:

@@ -26,7 +26,8 @@ def _worker(rank, world, port, q, seed, m, n, align):
     cols = column_range(n, world, rank, align)
     opts = lp_amd.InteriorPoint.default().opts()
     rc, x, fun, it, rows, coll = solve_column_split(np.ascontiguousarray(A[:, cols.start:cols.stop]), b,
-                                                    c[cols.start:cols.stop], n, 0.0, opts, want_log=True)
+                                                    c[cols.start:cols.stop], n, 0.0, opts, want_log=True,
+                                                    on_stream=True if os.environ.get("LPIPM_TEST_ON_STREAM") == "1" else None)
     q.put((rank, rc, cols.start, x.tolist(), fun, it, rows, coll.calls, coll.bytes))
     dist.barrier()
     dist.destroy_process_group()
@@ -98,3 +99,57 @@ def test_column_split_infeasible_agrees_on_all_ranks(ctx):
     rc, _, _, _, _ = ctx.solve_raw(lp_amd.InteriorPoint.default().opts())
     ctx.upload_arrays(A, b, c)
     assert rc == lp_amd._capi.INFEASIBLE
+
+
+def test_column_split_on_stream_contract(ctx):
+    """lpipm_set_collective_on_stream(1): the library does not drain before the callback (which here orders itself on
+    the stream it is handed).  Two gloo ranks on cuda:0, against the drained contract: bit-identical."""
+    import lp_amd
+    got_a = _run(2, 0, 256, 512, 128)
+    os.environ["LPIPM_TEST_ON_STREAM"] = "1"
+    try:
+        got_b = _run(2, 0, 256, 512, 128)
+    finally:
+        del os.environ["LPIPM_TEST_ON_STREAM"]
+    for a, b in zip(got_a, got_b):
+        assert a[1] == b[1] == 0 and a[5] == b[5] and a[3] == b[3] and a[4] == b[4]
+
+
+def test_split_over_too_many_ranks_is_refused_everywhere():
+    from lp_amd.colsplit import check_split, column_range
+    check_split(512, 4)
+    with pytest.raises(ValueError):
+        check_split(512, 8)                      # 4 column groups, 8 ranks: ranks 4..7 would hold nothing
+    assert len(column_range(512, 8, 7)) == 0
+
+
+def test_c5_two_ranks_on_one_gpu_at_c3_size_matches_golden(built):
+    """scripts/bench_c5.py: the strong-scaling harness of BASELINE config 5 with 2 ranks (gloo) sharing cuda:0 at
+    4096 x 8192, against the committed oracle vector of the headline LP."""
+    import json
+    import subprocess
+    port = 29500 + (os.getpid() * 11) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_c5.py"), "--rows", "4096", "--cols", "8192",
+           "--steps", "1", "--warmup", "0", "--backend", "gloo", "--one-gpu", "--seed", "0",
+           "--golden", os.path.join(ROOT, "tests", "golden", "planted_4096x8192_s0.npz")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["max_abs_err_vs_golden"] <= 1e-6
+    assert r["config"]["allreduce_MB_per_iteration"] > 60.0          # the packed lower block-triangle of M: 67.6 MB
+
+
+def test_bench_distributed_code_path_on_one_rank(built):
+    """bench.py's N > 1 code path (init_process_group nccl = RCCL, barrier, all-gather, max-over-ranks) on ONE rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, LPIPM_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29500 + (os.getpid() * 13) % 2000))
+    for extra in (["--m", "512", "--n", "1024", "--steps", "3", "--no-cpu-baseline"], ["--workload", "c4", "--steps", "1"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--warmup", "1"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert r["n_gpus"] == 1 and r["value"] > 0
