@@ -144,21 +144,37 @@ __global__ __launch_bounds__(256) void gemv_dual_kernel(const double* __restrict
         cacc[s] = (d2){0.0, 0.0};
     }
     __syncthreads();
-    for (int rr = wave; rr < GEMVT_ROWS; rr += 4) {
-        const double* row = A + (long long)(r0 + rr) * lda + c0 + 2 * lane;
-        const double vr = vrow[rr];
-        double racc = 0.0;
+    // RG rows per trip: their loads are all issued before any is used (RG * NS 16-byte loads in flight per lane) and
+    // the RG row sums go through the shuffle butterfly together
+    constexpr int RG = NS >= 8 ? 2 : 4;
+    for (int rr0 = wave * RG; rr0 < GEMVT_ROWS; rr0 += 4 * RG) {
+        d2 a[RG][NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (c0 + s * 128 + 2 * lane < np) {
-                const d2 a = *(const d2*)(row + s * 128);
-                racc += a[0] * wc[s][0] + a[1] * wc[s][1];
-                cacc[s] += a * vr;
+        for (int g = 0; g < RG; ++g) {
+            const double* row = A + (long long)(r0 + rr0 + g) * lda + c0 + 2 * lane;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                a[g][s] = c0 + s * 128 + 2 * lane < np ? *(const d2*)(row + s * 128) : (d2){0.0, 0.0};
+        }
+        double racc[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const double vr = vrow[rr0 + g];
+            racc[g] = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                racc[g] += a[g][s][0] * wc[s][0] + a[g][s][1] * wc[s][1];
+                cacc[s] += a[g][s] * vr;
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) racc += __shfl_xor(racc, off, 64);
-        if (lane == 0) AxPart[(long long)ch * mp + r0 + rr] = racc;
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int g = 0; g < RG; ++g) racc[g] += __shfl_xor(racc[g], off, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < RG; ++g) AxPart[(long long)ch * mp + r0 + rr0 + g] = racc[g];
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) *(d2*)&csum[wave][s * 128 + 2 * lane] = cacc[s];
