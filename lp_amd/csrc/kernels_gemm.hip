@@ -94,56 +94,67 @@ __device__ __forceinline__ void tile_coords(const GemmK& p, int t, int& ti, int&
 // Pp / Qp point at this thread's first staging element (row srow, column scol of the panels).
 // MTM x MTN = 16x16 MFMA tiles per wave (2x2 waves per workgroup): workgroup tile = 32*MTM x 32*MTN.
 //   4x4 -> 128x128 (throughput launches), 2x2 -> 64x64 and 1x4 -> 32x128 (latency-bound launches)
-template <bool SCALE, int MTM, int MTN>
+// PF register stages of global loads are in flight: k-tile k + PF is requested while k-tile k is multiplied, so a
+// load has PF - 1 whole k-tile periods to arrive.  With one stage (the first version) the small-tile launches of
+// the factorisation -- one round of tiles, nothing else on the CU -- ran at ~1.5 us per k-tile, the latency of an L2 /
+// Infinity-Cache load, against 0.43 us of MFMA work (trace: a K = 512 trailing update of 64x64 tiles 50 us).
+template <bool SCALE, int MTM, int MTN, int PF = (MTM * MTN >= 16 ? 2 : 3)>
 __device__ __forceinline__ void tile_mainloop(double (*ldsA)[32 * MTM][LDS_STRIDE], double (*ldsB)[32 * MTN][LDS_STRIDE],
                                               const double* __restrict__ Pp, long long ldp,
                                               const double* __restrict__ Qp, long long ldq,
                                               const double* __restrict__ s, int kb, int ke, d4 (&acc)[MTM][MTN],
                                               int srow, int scol, int wr, int wc, int fr, int fq) {
-    d2 sa[MTM], sb[MTN], sv = (d2){1.0, 1.0};
-    auto gload = [&](int kt) {
+    d2 sa[PF][MTM], sb[PF][MTN], sv[PF];
+    auto gload = [&](int kt, int st) {
         const long long ko = (long long)kt * BK;
 #pragma unroll
-        for (int r = 0; r < MTM; ++r) sa[r] = *(const d2*)(Pp + (long long)(32 * r) * ldp + ko);
+        for (int r = 0; r < MTM; ++r) sa[st][r] = *(const d2*)(Pp + (long long)(32 * r) * ldp + ko);
 #pragma unroll
-        for (int r = 0; r < MTN; ++r) sb[r] = *(const d2*)(Qp + (long long)(32 * r) * ldq + ko);
-        if (SCALE) sv = *(const d2*)(s + ko + scol);
+        for (int r = 0; r < MTN; ++r) sb[st][r] = *(const d2*)(Qp + (long long)(32 * r) * ldq + ko);
+        sv[st] = SCALE ? *(const d2*)(s + ko + scol) : (d2){1.0, 1.0};
     };
     // the scale is applied here, after the MFMAs of the current k-tile: multiplying right after the
     // loads would make the wave wait for the prefetch it has just issued
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int st) {
 #pragma unroll
-        for (int r = 0; r < MTM; ++r) *(d2*)&ldsA[buf][srow + 32 * r][scol] = sa[r];
+        for (int r = 0; r < MTM; ++r) *(d2*)&ldsA[buf][srow + 32 * r][scol] = sa[st][r];
 #pragma unroll
-        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = SCALE ? sb[r] * sv : sb[r];
+        for (int r = 0; r < MTN; ++r) *(d2*)&ldsB[buf][srow + 32 * r][scol] = SCALE ? sb[st][r] * sv[st] : sb[st][r];
     };
-    gload(kb);
-    lstore(0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kb + u < ke) gload(kb + u, u);
+    lstore(0, 0);
     __syncthreads();
     int cur = 0;
-    for (int kt = kb; kt < ke; ++kt) {
-        const bool more = kt + 1 < ke;
-        if (more) gload(kt + 1);
+    for (int kt0 = kb; kt0 < ke; kt0 += PF) {
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            d2 a[MTM], b[MTN];
+        for (int u = 0; u < PF; ++u) {          // k-tile kt0 + u lives in stage u and is in LDS buffer `cur`
+            const int kt = kt0 + u;
+            if (kt < ke) {
+                if (kt + PF < ke) gload(kt + PF, u);
 #pragma unroll
-            for (int mi = 0; mi < MTM; ++mi)
-                a[mi] = *(const d2*)&ldsA[cur][wr * (16 * MTM) + mi * 16 + fr][round * 8 + fq * 2];
+                for (int round = 0; round < 2; ++round) {
+                    d2 a[MTM], b[MTN];
 #pragma unroll
-            for (int nj = 0; nj < MTN; ++nj)
-                b[nj] = *(const d2*)&ldsB[cur][wc * (16 * MTN) + nj * 16 + fr][round * 8 + fq * 2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int mi = 0; mi < MTM; ++mi)
+                    for (int mi = 0; mi < MTM; ++mi)
+                        a[mi] = *(const d2*)&ldsA[cur][wr * (16 * MTM) + mi * 16 + fr][round * 8 + fq * 2];
 #pragma unroll
                     for (int nj = 0; nj < MTN; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+                        b[nj] = *(const d2*)&ldsB[cur][wc * (16 * MTN) + nj * 16 + fr][round * 8 + fq * 2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int mi = 0; mi < MTM; ++mi)
+#pragma unroll
+                            for (int nj = 0; nj < MTN; ++nj)
+                                acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+                }
+                if (kt + 1 < ke) lstore(cur ^ 1, (u + 1) % PF);
+                __syncthreads();
+                cur ^= 1;
+            }
         }
-        if (more) lstore(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
 }
 
