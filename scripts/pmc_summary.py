@@ -3,6 +3,7 @@ under profiles/: per-launch averages for one kernel, HBM-side traffic with the g
 /opt/skills/guides/MI355X_MICROARCH.md, MFMA busy fraction.
 usage: pmc_summary.py <kernel substring> <m> <n> <out.json> <dir with *_counter_collection.csv> [...]"""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 kern, m, n, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 vals = {}
 for d in sys.argv[5:]:
@@ -22,7 +23,9 @@ for k in list(vals):
     med = statistics.median(vals[k])
     vals[k] = [x for x in vals[k] if x >= 0.05 * med]
 avg = {k: sum(v) / len(v) for k, v in vals.items()}
-res = {"kernel": f"{kern} (A.diag(x/z).A^T, m={m} n={n}, lower 128x128 tiles)",
+from bench import csrc_hash
+res = {"kernel": f"{kern} (m={m} n={n})",
+       "csrc_sha256": csrc_hash(),     # bench.py reports these counters only while lp_amd/csrc still hashes to this
        "command": "rocprofv3 --pmc <COUNTERS> --output-format csv -- python3 scripts/prof_c3.py   (one pass per counter group)",
        "launches_averaged": {k: len(v) for k, v in vals.items()}}
 res.update({k + ("_KiB_raw" if k in ("FETCH_SIZE", "WRITE_SIZE") else ""): v for k, v in avg.items()})
@@ -30,10 +33,9 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     res["fetch_correction"] = ("x2: on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane coalesced loads "
                                "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact")
     res["traffic_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
-    res["algorithmic_bytes_per_launch"] = 8 * m * n + 4 * m * m
+    res["algorithmic_bytes_per_launch"] = 8 * m * n + (4 * m * m if "streamk" in kern else 0)
     res["note"] = ("FETCH_SIZE counts L2->fabric requests; Infinity-Cache (256 MiB) hits are included, so this is an upper "
-                   "bound on HBM bytes.  Floor for this tiling (8 L2s, one 8x8 super-block of tiles per XCD at a time): "
-                   "6 off-diagonal super-blocks x 16 panels + 4 diagonal x 8 panels of 8.4 MB = 1.07 GB + 0.13 GB of C")
+                   "bound on HBM bytes.")
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
     res["mfma_busy_fraction"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     res["mfma_busy_fraction_def"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 [cycles the kernel ran, per XCD] * 1024 SIMDs); "
