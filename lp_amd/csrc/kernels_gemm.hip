@@ -628,14 +628,15 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
 }
 
 // Canonical chunk of the A.D.A^T contraction in k-tiles: 128 columns up to n = 1024 (a small LP has few tiles: more,
-// shorter stream-K units fill more CUs), 256 columns (the reference dgemm's KC) up to n = 4096, 512 columns up to
-// n = 16384, 1024 above: a data-parallel tile's flush is a read-modify-write of its C tile that costs
-// ~10 us (C3: 2.27 / 2.33 / 2.55 ms per launch at 1024 / 512 / 256 columns, and 5.5e-7 / 1.2e-7 / 7.9e-8 / 6.3e-8 from
-// the planted vertex for one running sum / 1024 / 512 / 256).  LPIPM_ADAT_KC=<k-tiles> overrides it (measurement knob).
+// shorter stream-K units fill more CUs), 256 columns (the reference dgemm's KC) up to n = 4096, 1024 columns above.
+// A data-parallel tile's flush is a read-modify-write of its C tile (~10 us, and 256 KB of fabric traffic); measured at
+// C3 on one box, per launch and distance of the solve's x from the planted vertex:
+//   one running sum 5.5e-7 | 1024 columns 2.27 ms, 1.2e-7 | 512 columns 2.34 ms, 7.9e-8 | 256 columns 2.55 ms, 6.3e-8
+// (the oracle itself: 6.3e-8).  LPIPM_ADAT_KC=<k-tiles> overrides the rule (measurement knob).
 int gemm_streamk_chunk(int KT) {
     static const int forced = getenv("LPIPM_ADAT_KC") ? atoi(getenv("LPIPM_ADAT_KC")) : -1;
     if (forced >= 0) return forced == 0 ? (KT > 0 ? KT : 1) : forced;
-    return KT <= 64 ? 8 : (KT <= 256 ? 16 : (KT <= 1024 ? 32 : 64));
+    return KT <= 64 ? 8 : (KT <= 256 ? 16 : 64);
 }
 // chunk slots per tile for a contraction of KT k-tiles (1: no chunking, the tile is one running sum)
 static int streamk_cpt(int KT) {
