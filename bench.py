@@ -83,6 +83,13 @@ def cpu_baseline(A, b, c, m, n):
     it2 = r2["timing"]["total"] - it1
     per_it = 0.5 * r2["timing"]["total"]
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                   # the threads OpenBLAS actually runs (it caps its pool below the affinity mask)
+        from threadpoolctl import threadpool_info
+        blas = [t["num_threads"] for t in threadpool_info() if t.get("user_api") == "blas"]
+        if blas:
+            ncores = min(ncores, max(blas))
+    except Exception:
+        pass
     k = 3 if big else 6
     t1 = time.perf_counter()
     rs = oracle_np.solve(A, b, c, 0.0, oracle_np.Opts(max_iter=k))
