@@ -56,7 +56,8 @@ struct GemmK {
     double* ws;
     int nwg;
     unsigned int* sk_claim;   // see GemmArgs
-    int kc;                   // canonical summation chunk in k-tiles (0: plain running sum over the whole k-range)
+    int kc;                   // summation chunk of a data-parallel tile in k-tiles (0: plain running sum over the whole k-range)
+    int sk;                   // stream-K unit in k-tiles (== kc up to KT = 256: one canonical chunking for every tile)
     double* C2;               // nullable: the final value of every tile is stored here too (same ldc)
     BatchK bk;
 };
@@ -234,20 +235,7 @@ __device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned v
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)voff, (int)soff, 0);
 }
 
-// Chunk phase of tile t: 0 (common boundaries kc, 2 kc, ...).  A per-tile phase ((t mod 64)/16 * kc/4, so that the
-// two workgroups of a CU flush half a chunk apart) was measured and dropped: the data-parallel workgroups flushing
-// together is not what a flush costs (C3, kc = 16: 2.51 ms with the phases, 2.57 without; the lockstep batch lost
-// 10 % to the extra short chunks).  Kept as a function so that a chunking stays a property of the tile alone.
-__device__ __forceinline__ int chunk_phase(int, int) { return 0; }
-// chunk q of a tile with phase o: k-tiles [q == 0 ? 0 : o + (q-1) kc, o + q kc), clipped to KT (q = 0 is empty for o = 0)
-__device__ __forceinline__ void chunk_range(int o, int kc, int q, int KT, int& kb, int& ke) {
-    kb = q == 0 ? 0 : o + (q - 1) * kc;
-    ke = o + q * kc;
-    if (ke > KT) ke = KT;
-    if (kb > KT) kb = KT;
-}
-
-// One pass over the k-tiles [kb, ke) of a tile, in chunks that end at o + j*kc k-tiles (kc == 0: one chunk).
+// One pass over the k-tiles [kb, ke) of a tile, in chunks that end at multiples of kc k-tiles (kc == 0: one chunk).
 // The software pipeline (next k-tile prefetched into registers while the current one is multiplied out of LDS) runs
 // across chunk boundaries; the hot inner loop is the plain k-tile loop and the chunk logic lives around it:
 //   touch(first)  at the start of a chunk's last k-tile: may issue loads that pull the C tile towards L2
@@ -258,7 +246,7 @@ __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], d
                                              __amdgpu_buffer_rsrc_t Pr, unsigned p64, __amdgpu_buffer_rsrc_t Qr, unsigned q64,
                                              __amdgpu_buffer_rsrc_t Sr, unsigned offP, unsigned offQ, unsigned offS,
                                              int kb, int ke, d4 (&acc)[4][2],
-                                             int srow, int scol, int wr, int wc, int fr, int fq, int kc, int o, FL&& flush,
+                                             int srow, int scol, int wr, int wc, int fr, int fq, int kc, FL&& flush,
                                              TC&& touch) {
     d2 sa[2], sb[2], sv = (d2){1.0, 1.0};
     auto gload = [&](int kt) {
@@ -301,7 +289,7 @@ __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], d
     bool first = true;
     while (kt < ke) {
         int ce = ke;                                       // end of this chunk
-        if (kc > 0) { const int e = kt < o ? o : o + ((kt - o) / kc + 1) * kc; ce = e < ke ? e : ke; }
+        if (kc > 0) { const int e = (kt / kc + 1) * kc; ce = e < ke ? e : ke; }
         for (; kt < ce - 1; ++kt) {                        // the hot loop
             gload(kt + 1);
             mfma_ktile(cur);
@@ -420,15 +408,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         d4 acc[4][2];
         zero(acc);
         tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq,
-                            p.kc, chunk_phase(tile, p.kc), [&](bool first, bool last) {
+                            p.kc, [&](bool first, bool last) {
                                 if (first) store_tile(acc, ti, tj); else add_tile(acc, ti, tj, last && p.C2 != nullptr);
                             },
                             [&](bool first, unsigned& pf0, unsigned& pf1) { if (!first) touch_tile(ti, tj, pf0, pf1); });
     }
     if (ntiles_dp == p.ntiles) return;
     __shared__ int s_claim;
-    const int ch_tiles = p.kc > 0 ? p.kc : SK_CHUNK;
-    const int cpt = (KT + ch_tiles - 1) / ch_tiles + (p.kc > 0 ? 1 : 0);   // chunk slots per tile (phased tiles: one more)
+    const int ch_tiles = p.sk;
+    const int cpt = (KT + ch_tiles - 1) / ch_tiles;          // stream-K units per tile
     const int nchunks = (p.ntiles - ntiles_dp) * cpt;
     for (;;) {
         if (tid == 0) s_claim = (int)atomicAdd(p.sk_claim, 1u);
@@ -440,16 +428,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // row panels of A in L2 (tile-major order would have every unit load two panels of its own)
         const int nrem = p.ntiles - ntiles_dp;
         const int q = ch / nrem, rt = ch - q * nrem;
-        int kb, ke;
-        if (p.kc > 0) chunk_range(chunk_phase(ntiles_dp + rt, p.kc), p.kc, q, KT, kb, ke);
-        else { kb = q * SK_CHUNK; ke = kb + SK_CHUNK < KT ? kb + SK_CHUNK : KT; }
-        if (kb >= ke) continue;                                             // an empty slot
+        const int kb = q * ch_tiles, ke = kb + ch_tiles < KT ? kb + ch_tiles : KT;
         int ti, tj;
         tile_coords(p, ntiles_dp + rt, ti, tj);
         d4 acc[4][2];
         zero(acc);
         tile_pass_w8<SCALE>(ldsA, ldsB, p_rsrc(ti), p64, q_rsrc(tj), q64, Sr, offP, offQ, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq,
-                            0, 0, [&](bool, bool) {
+                            0, [&](bool, bool) {
             if (cpt == 1) { store_tile(acc, ti, tj); return; }   // the chunk is the whole tile
             const __amdgpu_buffer_rsrc_t wr_ = make_rsrc(p.ws + ((long long)rt * cpt + q) * (TILE * TILE), (unsigned)(TILE * TILE * sizeof(double)));
             const unsigned offW = (unsigned)(((wr * 64 + fq) * TILE + wc * 32 + fr) * sizeof(double));
@@ -598,14 +583,8 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
     const int ntiles_dp = (p.ntiles / p.nwg) * p.nwg;
     const int bx = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
     const int rt = bx / FIX_SPLIT, part = bx % FIX_SPLIT;
-    const int ch_tiles = p.kc > 0 ? p.kc : SK_CHUNK;
-    const int cpt = (p.KT + ch_tiles - 1) / ch_tiles + (p.kc > 0 ? 1 : 0);   // slab slots [rt*cpt, (rt+1)*cpt), one per chunk
-    int q0 = 0, q1 = cpt;                                                      // the non-empty ones: [q0, q1)
-    if (p.kc > 0) {
-        const int o = chunk_phase(ntiles_dp + rt, p.kc);
-        if (o == 0) q0 = 1;
-        while (q1 > q0 + 1 && o + (q1 - 2) * p.kc >= p.KT) --q1;
-    }
+    const int cpt = (p.KT + p.sk - 1) / p.sk;                // slabs [rt*cpt, (rt+1)*cpt), one per stream-K unit
+    const int q0 = 0, q1 = cpt;
     int ti, tj;
     tile_coords(p, ntiles_dp + rt, ti, tj);
     constexpr int PER = TILE * TILE / FIX_SPLIT;
@@ -638,14 +617,24 @@ int gemm_streamk_chunk(int KT) {
     if (forced >= 0) return forced == 0 ? (KT > 0 ? KT : 1) : forced;
     return KT <= 64 ? 8 : (KT <= 256 ? 16 : 64);
 }
-// chunk slots per tile for a contraction of KT k-tiles (1: no chunking, the tile is one running sum)
-static int streamk_cpt(int KT) {
+// Stream-K unit for a contraction of KT k-tiles: the canonical chunk up to KT = 256 (ONE chunking for data-parallel and
+// stream-K tiles: M's bits do not depend on the decomposition -- the sizes that run both alone and as lockstep batches);
+// above, 16 k-tiles whatever the data-parallel chunk: the launch ends one unit after the ideal time at best, and a unit
+// of 64 k-tiles is 0.24 ms (C3: the 16 stream-K tiles cost 0.25 ms for 3 % of the work).  Those tiles are then summed in
+// finer blocks than the data-parallel ones (same determinism, the decomposition-independence is given up for big LPs).
+static int streamk_unit(int KT) {
     const int kc = gemm_streamk_chunk(KT);
-    return KT <= kc ? 1 : (KT + kc - 1) / kc + 1;
+    return KT <= 256 ? kc : (kc < 16 ? kc : 16);
+}
+// stream-K units per tile (1: no split, the tile is one running sum)
+static int streamk_cpt(int KT) {
+    if (KT <= gemm_streamk_chunk(KT)) return 1;
+    const int u = streamk_unit(KT);
+    return (KT + u - 1) / u;
 }
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu) {
     const int cpt = streamk_cpt(KT);
-    const long long units = (long long)ntiles * (cpt > 1 ? cpt - 1 : 1);   // (tile, chunk) work units
+    const long long units = (long long)ntiles * cpt;   // (tile, unit) work items
     long long nwg = 2LL * num_cu;              // 2 resident workgroups per CU
     if (nwg > units) nwg = units;
     if (nwg < 1) nwg = 1;
@@ -664,7 +653,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.C = a.C; k.ldc = a.ldc; k.KT = a.K / BK; k.alpha = a.alpha; k.beta = a.beta;
     k.ntiles = a.ntiles; k.tiles_lower = a.tiles_lower; k.ntj = a.ntj; k.tile_list = a.tile_list;
     k.diag_pad_from = a.diag_pad_from; k.ws = a.ws; k.nwg = a.nwg; k.bk = batch_k(a.batch);
-    k.sk_claim = a.sk_claim; k.kc = 0; k.C2 = a.C2;
+    k.sk_claim = a.sk_claim; k.kc = 0; k.sk = SK_CHUNK; k.C2 = a.C2;
     const int B = a.batch.count;
     if (a.ntiles <= 0 || k.KT <= 0) return hipSuccess;
     if (!a.streamk) {   // one whole tile per workgroup
@@ -684,6 +673,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     k.kc = gemm_streamk_chunk(k.KT);
     if (k.KT <= k.kc) k.kc = 0;              // short contraction: one running sum per tile (and SK_CHUNK >= KT: whole tiles)
     if (k.kc == 0 && k.KT > SK_CHUNK) return hipErrorInvalidValue;
+    k.sk = k.kc == 0 ? SK_CHUNK : streamk_unit(k.KT);
     const int cpt = streamk_cpt(k.KT);
     const int nrem = a.ntiles - (a.ntiles / a.nwg) * a.nwg;
     if (a.C2 && (cpt == 1 || a.beta != 0.0)) return hipErrorInvalidValue;   // the second copy comes from a tile's last flush / the fix-up
