@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <unistd.h>
 #include "lpipm.h"
 
 struct LP { uint64_t m, n; std::vector<double> A, b, c, xs; };
@@ -65,7 +66,44 @@ int main() {
     const double Ainf[4] = {1, 1, 1, 1}, binf[1] = {-1}, cinf[4] = {1, 1, 1, 1};
     CHECK(lpipm_upload(ctx, 1, 4, Ainf, 4, binf, cinf, 0.0) == 0);
     CHECK(lpipm_solve(ctx, &o, x4, &f4, &it4, nullptr) == LPIPM_INFEASIBLE);
+    // round-2 entry points: one-iteration hook, one-read dual pass, symmetric residual
+    {
+        LP p = make(5, 100, 333);
+        CHECK(lpipm_upload(ctx, p.m, p.n, p.A.data(), p.n, p.b.data(), p.c.data(), 0.0) == 0);
+        std::vector<double> x(p.n, 1.5), y(p.m, 0.1), z(p.n, 0.7), dx(p.n), dy(p.m), dz(p.n), aw(p.m), atv(p.n);
+        double tau = 1.2, kappa = 0.8, dtk[2], alpha; int32_t info = -1; double ms;
+        CHECK(lpipm_k_iteration(ctx, &o, 0, x.data(), y.data(), z.data(), &tau, &kappa, dx.data(), dy.data(), dz.data(), dtk, &alpha, &info) == 0);
+        CHECK(info == 0 && alpha > 0.0 && alpha <= 1.0);
+        CHECK(lpipm_k_gemv_dual(ctx, x.data(), y.data(), aw.data(), atv.data(), 2, &ms) == 0);
+        const uint64_t ms_ = 200;
+        std::vector<double> S(ms_ * ms_), V(2 * ms_, 1.0), R0(2 * ms_, 0.5), Rho(2 * ms_);
+        for (uint64_t i = 0; i < ms_; ++i) for (uint64_t j = 0; j <= i; ++j) S[i * ms_ + j] = 1.0 / (1.0 + i + j);
+        CHECK(lpipm_k_symv_residual(ctx, ms_, S.data(), 2, V.data(), R0.data(), Rho.data()) == 0);
+    }
     lpipm_destroy(ctx);
+    // refined solves (LPIPM_REFINE=2) and the factorisation beside A.D.A^T (LPIPM_OVERLAP=1): both are decided when a
+    // context is created / first solves
+    setenv("LPIPM_REFINE", "2", 1);
+    setenv("LPIPM_OVERLAP", "1", 1);
+    {
+        lpipm_ctx* c2 = nullptr;
+        CHECK(lpipm_create(0, &c2) == 0);
+        LP p = make(9, 300, 700);
+        CHECK(lpipm_upload(c2, p.m, p.n, p.A.data(), p.n, p.b.data(), p.c.data(), 0.0) == 0);
+        std::vector<double> x(p.n); double fun; uint64_t it;
+        CHECK(lpipm_solve(c2, &o, x.data(), &fun, &it, nullptr) == 0);
+        CHECK(maxerr(x, p.xs) < 1e-5);
+        LP q = make(3, 2048, 2304);                       // big enough for the side-by-side schedule
+        CHECK(lpipm_upload(c2, q.m, q.n, q.A.data(), q.n, q.b.data(), q.c.data(), 0.0) == 0);
+        std::vector<double> xq(q.n);
+        CHECK(lpipm_solve(c2, &o, xq.data(), &fun, &it, nullptr) == 0);
+        CHECK(maxerr(xq, q.xs) < 1e-4);
+        CHECK(lpipm_upload(c2, p.m, p.n, p.A.data(), p.n, p.b.data(), p.c.data(), 0.0) == 0);   // back to a small geometry
+        CHECK(lpipm_solve(c2, &o, x.data(), &fun, &it, nullptr) == 0);
+        lpipm_destroy(c2);
+    }
     printf("host exerciser ok\n");
-    return 0;
+    fflush(stdout);
+    _exit(0);   // skip the HSA runtime's exit-time teardown: under ASan it trips a CHECK of the sanitizer's own device
+                // allocator ("dev_runtime_unloaded_"), which is not this library's code
 }
