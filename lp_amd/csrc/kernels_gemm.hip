@@ -624,6 +624,8 @@ int gemm_streamk_chunk(int KT) {
 // finer blocks than the data-parallel ones (same determinism, the decomposition-independence is given up for big LPs).
 static int streamk_unit(int KT) {
     const int kc = gemm_streamk_chunk(KT);
+    static const int forced = getenv("LPIPM_ADAT_SK") ? atoi(getenv("LPIPM_ADAT_SK")) : 0;   // measurement knob
+    if (forced > 0 && KT > 256) return forced;
     return KT <= 256 ? kc : (kc < 16 ? kc : 16);
 }
 // stream-K units per tile (1: no split, the tile is one running sum)
