@@ -1380,18 +1380,23 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
     }
     if (ms_out) *ms_out = total / repeats;
     if (getenv("LPIPM_DIAG_STAMPS")) {  // debug aid: cycle stamps of the first diagonal-block kernel
-        long long* d = nullptr; long long h[16] = {0};
+        long long* d = nullptr; long long h[64] = {0};
         if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
             g_diag_stamps = d;
+            (void)hipMemset(d, 0, sizeof(h));
             (void)hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st);
             (void)launch_potrf(c->kM, mp, mp, c->kplan, c->kinfo, c->st);
             (void)hipStreamSynchronize(c->st);
             g_diag_stamps = nullptr;
             (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
             (void)hipFree(d);
-            fprintf(stderr, "diag stamps (cycles): elim(0) %lld, priority update(0) %lld, elim(1)||rest(0) %lld, whole factorisation %lld, write inverses %lld\n",
-                    h[1]-h[0], h[2]-h[1], h[3]-h[2], h[6]-h[0], h[7]-h[6]);
-
+            fprintf(stderr, "diag stamps (cycles): E(0) %lld, P tile + wait for all eight on wave 0 %lld, barrier to barrier (k = 1) %lld, "
+                    "all block columns %lld, last stores %lld\n  k = 1, cycles after the barrier, per wave: P tile done",
+                    h[1]-h[0], h[2]-h[1], h[3]-h[1], h[6]-h[0], h[7]-h[6]);
+            for (int w = 0; w < 16; ++w) fprintf(stderr, " %lld", h[32 + w] - h[1]);
+            fprintf(stderr, "\n  at the next barrier");
+            for (int w = 0; w < 16; ++w) fprintf(stderr, " %lld", h[16 + w] - h[1]);
+            fprintf(stderr, "\n");
         }
     }
     int32_t info = 0;
