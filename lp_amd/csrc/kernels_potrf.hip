@@ -650,12 +650,14 @@ hipError_t potrf_panel_chain(double* M, int64_t ld, int mp, const FactorPlan& pl
         if (e != hipSuccess) return e;
         const int ncols = J1 - j - 1;            // column blocks of the outer panel right of j
         if (ncols > 0) {
-            // rows j+1..nb x columns j+1..J1-1 -= L[rows, j] . L[cols, j]^T  (rectangular grid of
-            // 64x64 tiles; the few tiles above the diagonal are computed too and never read)
+            // rows j+1..nb x columns j+1..J1-1 -= L[rows, j] . L[cols, j]^T  (rectangular grid of tiles; the few tiles
+            // above the diagonal are computed too and never read)
             GemmArgs c{};
             c.P = panel; c.ldp = ld; c.Q = panel; c.ldq = ld; c.s = nullptr;
             c.C = M + (o + NB) * ld + (o + NB); c.ldc = ld; c.K = NB; c.alpha = -1.0; c.beta = 1.0;
-            c.tile_edge = 64; c.tiles_lower = 0; c.ntj = 2 * ncols; c.ntiles = (2 * rem) * (2 * ncols);
+            // 32x32 tiles: 16x as many workgroups as 128x128 ones, 32 MFMAs per wave; the launch is one round of tiles on the
+            // chain (factorisation at m = 4096: 1998 us with 64x64 tiles, 1942 with 32x64, 1903 with 32x32)
+            c.tile_edge = 3232; c.tiles_lower = 0; c.ntj = 4 * ncols; c.ntiles = (4 * rem) * (4 * ncols);
             c.tile_list = nullptr; c.diag_pad_from = -1; c.ws = nullptr; c.nwg = c.ntiles; c.batch = bt;
             e = launch_gemm_nt(c, st);
             if (e != hipSuccess) return e;
@@ -677,7 +679,10 @@ hipError_t potrf_trailing_update(double* M, int64_t ld, int mp, hipStream_t st, 
     // 64x64 tiles (4 workgroups per CU) until the 128x128 ones would fill the chip's 512 slots about twice:
     // below that a launch lasts one K = 512 tile (~150 us at 128, ~60 at 64) whatever its tile count
     // (factorisation at m = 4096: 2400 -> 2311 us)
-    if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
+    // up to 16 trailing blocks (at most one round of 64x64 tiles) 32x32 tiles: the launch lasts as long as the busiest CU's
+    // tiles, and a quarter-size tile is a quarter-length MFMA chain (m = 4096: 1889 -> 1858 us, m = 2048: 772 -> 745)
+    if (remT <= 16)                        { u.tile_edge = 3232; u.ntiles = (4 * remT) * (4 * remT + 1) / 2; }
+    else if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
     else                             { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
     u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles; u.batch = bt;
     return launch_gemm_nt(u, st);

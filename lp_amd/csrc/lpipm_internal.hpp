@@ -100,7 +100,7 @@ struct GemmArgs {
                                 //   (workgroups that finish their data-parallel tiles early take more of them); slabs are
                                 //   indexed by chunk, so the sums do not depend on who computed what
     double*       C2;           // stream-K launches whose tiles are all split (ntiles < nwg): final values stored here too
-    int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols
+    int           tile_edge;    // whole-tile launches: 0/128 -> 128x128 tiles, 64 -> 64x64, 32 -> 32 rows x 128 cols, 3232 -> 32x32
     Batch         batch;        // lockstep batch (every pointer above except tile_list is per LP)
 };
 // Launches the main kernel and, when tiles are split into stream-K chunks, the deterministic fix-up pass.
