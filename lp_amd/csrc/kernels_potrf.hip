@@ -666,26 +666,37 @@ hipError_t potrf_panel_chain(double* M, int64_t ld, int mp, const FactorPlan& pl
     return hipSuccess;
 }
 
-// Right-looking trailing update behind the outer panel [J0, J1): A22 -= L21 . L21^T with K = (J1 - J0) * 128.
-hipError_t potrf_trailing_update(double* M, int64_t ld, int mp, hipStream_t st, const Batch& bt, int J0, int J1) {
-    const int nb = mp / NB;
-    const int remT = nb - J1;                    // trailing blocks beyond the outer panel
-    if (remT <= 0) return hipSuccess;
-    const int64_t oJ0 = (int64_t)J0 * NB, oJ1 = (int64_t)J1 * NB;
+// Right-looking trailing update behind the outer panel [J0, J1): A22 -= L21 . L21^T with K = (J1 - J0) * 128, restricted to
+// the block columns [C0, C1) of the trailing matrix (C0 >= J1; rows >= the column's own block).
+//   whole update: C0 = J1, C1 = nb.  Look-ahead: [J1, J1 + OUTER) first -- all the next outer panel reads -- and the rest on a
+//   side stream beside that panel's chain.
+static hipError_t trailing_update_columns(double* M, int64_t ld, int nb, hipStream_t st, const Batch& bt, int J0, int J1,
+                                          int C0, int C1) {
+    if (C0 >= C1) return hipSuccess;
+    const int64_t oJ0 = (int64_t)J0 * NB, oC0 = (int64_t)C0 * NB;
+    const int remT = nb - C0;                    // block rows from C0 down
     GemmArgs u{};
-    u.P = M + oJ1 * ld + oJ0; u.ldp = ld; u.Q = u.P; u.ldq = ld; u.s = nullptr;
-    u.C = M + oJ1 * ld + oJ1; u.ldc = ld; u.K = (J1 - J0) * NB; u.alpha = -1.0; u.beta = 1.0;
-    u.tiles_lower = 1; u.ntj = 0; u.tile_list = nullptr;
-    // 64x64 tiles (4 workgroups per CU) until the 128x128 ones would fill the chip's 512 slots about twice:
-    // below that a launch lasts one K = 512 tile (~150 us at 128, ~60 at 64) whatever its tile count
-    // (factorisation at m = 4096: 2400 -> 2311 us)
-    // up to 16 trailing blocks (at most one round of 64x64 tiles) 32x32 tiles: the launch lasts as long as the busiest CU's
-    // tiles, and a quarter-size tile is a quarter-length MFMA chain (m = 4096: 1889 -> 1858 us, m = 2048: 772 -> 745)
-    if (remT <= 16)                        { u.tile_edge = 3232; u.ntiles = (4 * remT) * (4 * remT + 1) / 2; }
-    else if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
-    else                             { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
-    u.diag_pad_from = -1; u.ws = nullptr; u.nwg = u.ntiles; u.batch = bt;
+    u.s = nullptr; u.ldp = ld; u.ldq = ld; u.ldc = ld; u.K = (J1 - J0) * NB; u.alpha = -1.0; u.beta = 1.0;
+    u.tile_list = nullptr; u.diag_pad_from = -1; u.ws = nullptr; u.batch = bt;
+    u.P = M + oC0 * ld + oJ0; u.Q = u.P; u.C = M + oC0 * ld + oC0;
+    if (C1 < nb) {
+        // a band of columns: rectangular grid of 32x32 tiles, rows C0..nb x columns C0..C1 (the few tiles above the diagonal
+        // are computed too and never read); it sits on the chain, and a 32x32 tile is the shortest MFMA chain there is
+        u.tile_edge = 3232; u.tiles_lower = 0; u.ntj = 4 * (C1 - C0); u.ntiles = (4 * remT) * (4 * (C1 - C0));
+    } else {
+        u.tiles_lower = 1; u.ntj = 0;
+        // up to 16 trailing blocks (at most one round of 64x64 tiles) 32x32 tiles: the launch lasts as long as the busiest CU's
+        // tiles, and a quarter-size tile is a quarter-length MFMA chain (m = 4096: 1889 -> 1858 us, m = 2048: 772 -> 745);
+        // 64x64 tiles (4 workgroups per CU) until the 128x128 ones would fill the chip's 512 slots about twice
+        if (remT <= 16)                        { u.tile_edge = 3232; u.ntiles = (4 * remT) * (4 * remT + 1) / 2; }
+        else if (remT * (remT + 1) / 2 < 1024) { u.tile_edge = 64; u.ntiles = (2 * remT) * (2 * remT + 1) / 2; }
+        else                                   { u.tile_edge = 128; u.ntiles = remT * (remT + 1) / 2; }
+    }
+    u.nwg = u.ntiles;
     return launch_gemm_nt(u, st);
+}
+hipError_t potrf_trailing_update(double* M, int64_t ld, int mp, hipStream_t st, const Batch& bt, int J0, int J1) {
+    return trailing_update_columns(M, ld, mp / NB, st, bt, J0, J1, J1, mp / NB);
 }
 
 // inverses of the diagonal super-blocks from the 128-block inverses: doubling levels, each a
@@ -699,15 +710,41 @@ hipError_t potrf_superblock_inverses(const FactorPlan& plan, hipStream_t st, con
 }
 
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
-                        const Batch& bt) {
+                        const Batch& bt, const PotrfLookahead* la) {
     hipError_t e = potrf_clear_info(info, st, bt);
     if (e != hipSuccess) return e;
     const int nb = mp / NB;
-    for (int J0 = 0; J0 < nb; J0 += OUTER) {
+    // Look-ahead (one LP, enough trailing matrix for it to matter): behind outer panel p the block columns of panel p+1 are
+    // updated on the chain stream and the chain goes on; the rest of the update runs on the side stream beside it and has to
+    // be complete only before panel p+1's own trailing update touches the same columns.  OPT-IN (LPIPM_LOOKAHEAD=1): measured
+    // at m = 4096 1910 -> 1855 us with 8 CUs per XCC kept free for the chain, 1870 with 4, 1890 with 2, 1905 with a
+    // low-priority unmasked side stream; at m = 2048 750 -> 775 whatever the setting.  Trace: the chain's part of the update is
+    // one round of K = 512 tiles (45 us where the whole update takes 105), and the chain's next panel solve and inner update
+    // take 2-4x as long beside the side stream's workgroups (26 and 46 us instead of 10): 270 us per outer panel against 275.
+    const int npanel = (nb + OUTER - 1) / OUTER;
+    const bool ahead = la && la->side && bt.count == 1 && (int)la->ev_chain.size() >= npanel && nb >= 3 * OUTER;
+    int pending = -1;                            // panel whose rest-update the chain stream has not waited for yet
+    for (int J0 = 0, pnl = 0; J0 < nb; J0 += OUTER, ++pnl) {
         const int J1 = J0 + OUTER < nb ? J0 + OUTER : nb;
         if ((e = potrf_panel_chain(M, ld, mp, plan, info, st, bt, J0, J1)) != hipSuccess) return e;
-        if ((e = potrf_trailing_update(M, ld, mp, st, bt, J0, J1)) != hipSuccess) return e;
+        if (J1 >= nb) break;
+        const int J2 = J1 + OUTER < nb ? J1 + OUTER : nb;
+        if (ahead && J2 < nb) {
+            if (pending >= 0 && (e = hipStreamWaitEvent(st, la->ev_rest[pending], 0)) != hipSuccess) return e;
+            if ((e = trailing_update_columns(M, ld, nb, st, bt, J0, J1, J1, J2)) != hipSuccess) return e;
+            // the rest starts once the chain stream's part is done: side by side the two halve each other and the chain waits
+            // as long as for the whole update (trace: 103 us instead of 12)
+            if ((e = hipEventRecord(la->ev_chain[pnl], st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(la->side, la->ev_chain[pnl], 0)) != hipSuccess) return e;
+            if ((e = trailing_update_columns(M, ld, nb, la->side, bt, J0, J1, J2, nb)) != hipSuccess) return e;
+            if ((e = hipEventRecord(la->ev_rest[pnl], la->side)) != hipSuccess) return e;
+            pending = pnl;
+        } else {
+            if (pending >= 0) { if ((e = hipStreamWaitEvent(st, la->ev_rest[pending], 0)) != hipSuccess) return e; pending = -1; }
+            if ((e = trailing_update_columns(M, ld, nb, st, bt, J0, J1, J1, nb)) != hipSuccess) return e;
+        }
     }
+    if (pending >= 0 && (e = hipStreamWaitEvent(st, la->ev_rest[pending], 0)) != hipSuccess) return e;
     return potrf_superblock_inverses(plan, st, bt);
 }
 

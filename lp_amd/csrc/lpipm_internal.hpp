@@ -159,8 +159,14 @@ void factor_plan_destroy(FactorPlan& plan);
 // In-place blocked lower Cholesky of the mp x mp row-major matrix M (mp multiple of NB), followed by
 // the inverses of the diagonal super-blocks (plan).  info (device int32): 0, or 1 + index of the
 // first non-positive pivot.
+// Look-ahead for the trailing updates of a single factorisation: `side` is a second stream (CU-masked, so that the chain
+// always finds free CUs), ev_chain / ev_rest one event per outer panel.  nullptr: everything on `st`.
+struct PotrfLookahead {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_chain, ev_rest;
+};
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
-                        const Batch& bt = Batch{});
+                        const Batch& bt = Batch{}, const PotrfLookahead* la = nullptr);
 
 // The pieces of launch_potrf, for the factorisation that runs beside A.D.A^T (solver.hip, enqueue_factor_overlapped):
 constexpr int POTRF_OUTER = 4;   // 128-blocks per outer panel

@@ -65,6 +65,7 @@ struct lpipm_ctx {
     uint64_t overlap_sections = 0;       // profiling: sections enqueued in this solve
     std::vector<int> grp_off, grp_nt;    // tile sub-list of every column group (outer panel of the factorisation)
     hipEvent_t ev_fork = nullptr;
+    PotrfLookahead la;                   // trailing updates of one factorisation beside the next panel's chain (launch_potrf)
     std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
     int refine = -1;             // -1: decide from the environment at first use.  0 (default): plain solves; LPIPM_REFINE=2: every
                                  //   solve of every iteration refined; =1: only from mu / mu_0 <= refine_below() on.
@@ -300,6 +301,36 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
             }
         }
     }
+    // Side stream for the look-ahead of the factorisation's trailing updates (launch_potrf): OPT-IN, LPIPM_LOOKAHEAD=1 (see
+    // there for the measurements).  CU-masked (bit i = CU i/8 of XCC i%8): the first R CUs of every XCC stay free for the chain
+    // stream's kernels -- the diagonal-block kernel needs a CU to itself (150 KB of LDS) and would otherwise wait for a
+    // side-stream tile to drain.  LPIPM_LOOKAHEAD_CUS=R sets R (default 8; 0: an unmasked low-priority stream).
+    {
+        const char* on = getenv("LPIPM_LOOKAHEAD");
+        int R = 8;
+        if (const char* e = getenv("LPIPM_LOOKAHEAD_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 16) R = v; }
+        if (on && on[0] == '1' && c->num_cu == 256) {
+            uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 256; ++i) if ((i / 8) >= R) mk[i / 32] |= 1u << (i % 32);
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority (numerically largest)
+            hipError_t e = R > 0 ? hipExtStreamCreateWithCUMask(&c->la.side, 8, mk) : hipStreamCreateWithPriority(&c->la.side, hipStreamNonBlocking, lo);
+            constexpr int NEV = 64;              // outer panels of the largest factorisation (m <= 32768)
+            for (int i = 0; i < 2 * NEV && e == hipSuccess; ++i) {
+                hipEvent_t ev = nullptr;
+                e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e == hipSuccess) (i < NEV ? c->la.ev_chain : c->la.ev_rest).push_back(ev);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (hipEvent_t ev : c->la.ev_chain) (void)hipEventDestroy(ev);
+                for (hipEvent_t ev : c->la.ev_rest) (void)hipEventDestroy(ev);
+                c->la.ev_chain.clear(); c->la.ev_rest.clear();
+                if (c->la.side) (void)hipStreamDestroy(c->la.side);
+                c->la.side = nullptr;
+            }
+        }
+    }
     *out = c;
     return LPIPM_OK;
 }
@@ -325,6 +356,9 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     for (hipEvent_t e : c->ev_ready) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chain) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_adat) (void)hipEventDestroy(e);
+    if (c->la.side) { (void)hipStreamSynchronize(c->la.side); (void)hipStreamDestroy(c->la.side); }
+    for (hipEvent_t e : c->la.ev_chain) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->la.ev_rest) (void)hipEventDestroy(e);
     if (c->st_a) { (void)hipStreamSynchronize(c->st_a); (void)hipStreamDestroy(c->st_a); }
     if (c->st_b) { (void)hipStreamSynchronize(c->st_b); (void)hipStreamDestroy(c->st_b); }
     if (c->status_host) (void)hipHostFree(c->status_host);
@@ -767,6 +801,9 @@ static int enqueue_head(lpipm_ctx* c) {
     return LPIPM_OK;
 }
 
+// The look-ahead of launch_potrf needs a second stream: not while a graph is being captured on the solver's stream.
+static const PotrfLookahead* lookahead(lpipm_ctx* c) { return (c->la.side && c->use_graph != 1) ? &c->la : nullptr; }
+
 // The rest of the iteration, ending with the status record on its way to the host and ev_status behind it.
 static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     VecArgs& v = c->va;
@@ -776,7 +813,7 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const Batch& bt = c->bt;
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (c->factor_in_head) {}                                                             // factorised beside A.D.A^T
-    else if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt));   // :129-131
+    else if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt, lookahead(c)));   // :129-131
     else           LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
@@ -1371,7 +1408,7 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
     for (int r = 0; r < repeats; ++r) {
         LP_HIP(hipMemcpyAsync(c->kM, c->kM0, (size_t)mp * mp * sizeof(double), hipMemcpyDeviceToDevice, c->st));
         LP_HIP(hipEventRecord(c->ev_begin, c->st));
-        LP_HIP(launch_potrf(c->kM, mp, mp, c->kplan, c->kinfo, c->st));
+        LP_HIP(launch_potrf(c->kM, mp, mp, c->kplan, c->kinfo, c->st, Batch{}, lookahead(c)));
         LP_HIP(hipEventRecord(c->ev_end, c->st));
         LP_HIP(hipStreamSynchronize(c->st));
         float ms = 0.f;

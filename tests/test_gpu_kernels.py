@@ -81,6 +81,27 @@ def test_potrf_reports_nonpositive_pivot(ctx):
     assert 1 <= info <= 151
 
 
+def test_potrf_lookahead_is_bit_identical(built, monkeypatch):
+    """LPIPM_LOOKAHEAD=1 (trailing updates split: the next outer panel's columns on the chain stream, the rest on a CU-masked
+    side stream behind events; opt-in) must give the factor of the serial schedule bit for bit: every element is
+    the same k-ordered sum whatever the tile shapes and the streams."""
+    import lp_amd
+    m = 2048
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((m, m + 9))
+    M = B @ B.T
+    serial = lp_amd.Context(0)
+    L0, info0, _ = serial.k_potrf(M)
+    serial.close()
+    monkeypatch.setenv("LPIPM_LOOKAHEAD", "1")
+    ahead = lp_amd.Context(0)
+    for _ in range(3):
+        L1, info1, _ = ahead.k_potrf(M)
+        assert info0 == 0 and info1 == 0
+        assert np.array_equal(np.tril(L0), np.tril(L1))
+    ahead.close()
+
+
 @pytest.mark.parametrize("m,n", SHAPES)
 def test_gemv_n_t(ctx, m, n):
     """A.w and A^T.v (feasible_point.rs:122-123, newton_equations.rs:220,223): 1e-13*sqrt(k) relative."""
