@@ -337,33 +337,22 @@ __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mbl
     int my_simd;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 4, 2)" : "=s"(my_simd));
 
-    for (int e = tid * 2; e < NB * NB; e += 2 * DT) {
-        const int r = e >> 7, c = e & 127;
-        d2 v = *(const d2*)(Mblk + (long long)r * ld + c);
-        if (c > r) v[0] = 0.0;
-        if (c + 1 > r) v[1] = 0.0;
-        *(d2*)&Ls[r][c] = v;
+    // The image: 8 pairs per thread, all requested before anything else -- a loop of load / mask / LDS store paid one global
+    // round trip per pair (6700 cycles of prologue, 9000 with the role set-up behind it) -- and stored once the roles below
+    // have been worked out in their shadow (lds_barrier does not wait for vmcnt): 5000.
+    d2 img[NB * NB / (2 * DT)];
+#pragma unroll
+    for (int i = 0; i < NB * NB / (2 * DT); ++i) {
+        const int e = tid * 2 + i * 2 * DT;
+        img[i] = *(const d2*)(Mblk + (long long)(e >> 7) * ld + (e & 127));
     }
     if (tid < SB * SB) eye[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
     if (lane == 0) wsimd[wave] = my_simd;
     if (tid < NSB) { pdone[tid] = 0; ready[tid] = 0; }
-    if (wave < NSB - 1 && lane < 32) {
-        // the R tiles of block column j = wave as LDS byte offsets {C tile, row operand, its row stride, column operand}; entries
-        // past the last tile (always including 31) are a harmless dummy.  Built here, in the shadow of the global loads.
-        const int j = wave, c0 = j * SB, nb16 = (NB - c0 - SB) / SB;
-        const int nR = nb16 * (nb16 - 1) / 2 + (j + 1) * (nb16 - 1);
-        TileAddr x = {0, 0, LS, &Ls[0][0]};
-        if (lane < nR) tile_decode<false>(Ls, xid[j & 1], j, lane, x.crow, x.ccol, x.ap, x.astride);
-        ttab[j][lane][0] = (int)lds_off(&Ls[x.crow][x.ccol]);
-        ttab[j][lane][1] = (int)lds_off(x.ap);
-        ttab[j][lane][2] = x.astride * 8;
-        ttab[j][lane][3] = (int)lds_off(&Ls[x.ccol][c0]);
-    }
     lds_barrier();
     // Roles beside the elimination.  FP64 MFMA and v_fma_f64 share a SIMD's double-precision pipe and the eliminating wave
-    // runs at priority 3, so the waves on its SIMD stay out of the way.  On every other SIMD the first wave streams the
-    // MFMA tiles (one wave keeps the pipe busy: a dependent v_mfma_f64_16x16x4 issues every ~85 cycles, the pipe takes one
-    // per ~75; four waves in step on one SIMD only took turns), the others do the global stores.
+    // runs at priority 3, so the waves on its SIMD stay out of the way.  On every other SIMD the first two waves stream the
+    // MFMA tiles (with four waves in step on one SIMD the chains only took turns), the others do the global stores.
     // role: -1 none, 0..: MFMA worker index, 16 + i: store worker i.
     if (wave == 0 && lane < NW) {
         const int sm = wsimd[lane];
@@ -375,6 +364,25 @@ __global__ __launch_bounds__(DT) void potrf_diag_kernel(double* __restrict__ Mbl
         const unsigned long long below = (1ull << lane) - 1ull;
         wrole[lane] = kind < 0 ? -1 : (kind == 0 ? __popcll(mm & below) : 16 + __popcll(ms & below));
         if (lane == 0) { nrole[0] = __popcll(mm); nrole[1] = __popcll(ms); }
+    } else if (wave >= 1 && wave < NSB && lane < 32) {
+        // the R tiles of block column j as LDS byte offsets {C tile, row operand, its row stride, column operand}; entries
+        // past the last tile (always including 31) are a harmless dummy
+        const int j = wave - 1, c0 = j * SB, nb16 = (NB - c0 - SB) / SB;
+        const int nR = nb16 * (nb16 - 1) / 2 + (j + 1) * (nb16 - 1);
+        TileAddr x = {0, 0, LS, &Ls[0][0]};
+        if (lane < nR) tile_decode<false>(Ls, xid[j & 1], j, lane, x.crow, x.ccol, x.ap, x.astride);
+        ttab[j][lane][0] = (int)lds_off(&Ls[x.crow][x.ccol]);
+        ttab[j][lane][1] = (int)lds_off(x.ap);
+        ttab[j][lane][2] = x.astride * 8;
+        ttab[j][lane][3] = (int)lds_off(&Ls[x.ccol][c0]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB * NB / (2 * DT); ++i) {
+        const int e = tid * 2 + i * 2 * DT, r = e >> 7, c = e & 127;
+        d2 v = img[i];
+        if (c > r) v[0] = 0.0;
+        if (c + 1 > r) v[1] = 0.0;
+        *(d2*)&Ls[r][c] = v;
     }
     lds_barrier();
     const int role = __builtin_amdgcn_readfirstlane(wrole[wave]), n_mw = __builtin_amdgcn_readfirstlane(nrole[0]),
