@@ -625,6 +625,23 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_grouped64_kernel(const GemmTil
     tile_store<2, 2>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
 }
 
+// And with 32x32 output tiles: the merge stages of one LP are one round of tiles each, so a stage lasts as long as its longest
+// k-loop, and a quarter-size tile has the shortest MFMA chain and the tightest triangular k-range.
+__global__ __launch_bounds__(256, 4) void gemm_nt_grouped32_kernel(const GemmTileDesc* __restrict__ descs, BatchK bk) {
+    if (batch_done(bk)) return;
+    __shared__ __attribute__((aligned(16))) double ldsA[2][32][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][32][LDS_STRIDE];
+    TILE_THREAD_IDS
+    GemmTileDesc d = descs[blockIdx.x];
+    d.P = batch_ptr(d.P, bk); d.Q = batch_ptr(d.Q, bk); d.C = batch_ptr(d.C, bk);
+    d4 acc[1][1];
+    acc[0][0] = (d4){0.0, 0.0, 0.0, 0.0};
+    tile_mainloop<false, 1, 1>(ldsA, ldsB, d.P + (long long)srow * d.ldp + scol, d.ldp, d.Q + (long long)srow * d.ldq + scol,
+                               d.ldq, nullptr, d.kt_begin, d.kt_end, acc, srow, scol, wr, wc, fr, fq);
+    double* cb = d.C + (long long)(wr * 16 + fq) * d.ldc + (wc * 16 + fr);
+    tile_store<1, 1>(cb, d.ldc, acc, d.alpha, 0.0, false, 0, -1, fr, fq);
+}
+
 // Adds the chunk slabs of every stream-K (remainder) tile in chunk order.  grid = remainder tiles x FIX_SPLIT:
 // a tile can have dozens of slabs, so its 16K elements are spread over FIX_SPLIT workgroups (8 rows each) to
 // keep this pass off the critical path.
@@ -757,7 +774,8 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
 
 hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt, int edge) {
     if (ntiles <= 0) return hipSuccess;
-    if (edge == 64) hipLaunchKernelGGL(gemm_nt_grouped64_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
+    if (edge == 32)      hipLaunchKernelGGL(gemm_nt_grouped32_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
+    else if (edge == 64) hipLaunchKernelGGL(gemm_nt_grouped64_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
     else            hipLaunchKernelGGL(gemm_nt_grouped_kernel, dim3(ntiles, 1, bt.count), dim3(256), 0, st, descs_dev, batch_k(bt));
     return hipGetLastError();
 }

@@ -59,7 +59,7 @@ hipError_t factor_plan_create(FactorPlan& plan, const double* L, int64_t ld, int
     factor_plan_destroy(plan);
     plan.mp = mp;
     plan.super_w = super_w;
-    plan.merge_edge = merge_edge == 64 ? 64 : 128;
+    plan.merge_edge = (merge_edge == 64 || merge_edge == 32) ? merge_edge : 128;
     const int E = plan.merge_edge, SUB = NB / E, EK = E / BK;   // sub-tiles per 128-block edge, k-tiles per sub-tile edge
     hipError_t e;
     for (int r0 = 0; r0 < mp; r0 += super_w) {

@@ -135,7 +135,7 @@ struct SuperBlock {
 };
 struct FactorPlan {
     int mp = 0;
-    int merge_edge = 128;    // output tile edge of the merge GEMMs (64: latency-bound single LP, 128: flop-bound batch)
+    int merge_edge = 128;    // output tile edge of the merge GEMMs (32 / 64: latency-bound, 128: flop-bound)
     int super_w = SUPER;     // width of the diagonal super-blocks whose inverses are formed: wider = fewer, fully
                              // parallel solve steps, but the merge GEMMs cost flops (a batch that already fills
                              // the chip prefers 512)

@@ -412,8 +412,10 @@ static int super_for(int mp) {
     return mp <= 2048 ? 512 : SUPER;
 }
 static int merge_edge_for(int) {
-    if (const char* e = getenv("LPIPM_MERGE_EDGE")) return atoi(e) == 128 ? 128 : 64;
-    return 64;
+    // 32x32 merge tiles: a stage is one round of tiles on the chain (factorisation m = 512: 194 -> 177 us, 1024: 364 -> 346,
+    // 4096: 1865 -> 1854; the lockstep C4 batch is indifferent: 1745 LP/s either way)
+    if (const char* e = getenv("LPIPM_MERGE_EDGE")) { const int v = atoi(e); return (v == 128 || v == 64) ? v : 32; }
+    return 32;
 }
 
 // Per-LP device state: one pass over a measuring arena sizes it, a second pass over the real one places it.
