@@ -81,6 +81,24 @@ def test_potrf_reports_nonpositive_pivot(ctx):
     assert 1 <= info <= 151
 
 
+def test_potrf_is_bitwise_reproducible(ctx):
+    """The diagonal-block kernel hands its tiles to waves according to the SIMD each wave landed on (hardware placement
+    starts at a varying SIMD): who computes a tile must not change what is computed.  30 factorisations of one matrix,
+    bit for bit; the solve through the inverses it also produces likewise."""
+    m = 640
+    rng = np.random.default_rng(23)
+    B = rng.standard_normal((m, m + 17))
+    M = B @ B.T
+    R = rng.standard_normal((2, m))
+    L0, info, _ = ctx.k_potrf(M)
+    V0, _ = ctx.k_chol_solve(m, R)
+    assert info == 0
+    for _ in range(30):
+        L, info, _ = ctx.k_potrf(M)
+        V, _ = ctx.k_chol_solve(m, R)
+        assert info == 0 and np.array_equal(np.tril(L), np.tril(L0)) and np.array_equal(V, V0)
+
+
 def test_potrf_lookahead_is_bit_identical(built, monkeypatch):
     """LPIPM_LOOKAHEAD=1 (trailing updates split: the next outer panel's columns on the chain stream, the rest on a CU-masked
     side stream behind events; opt-in) must give the factor of the serial schedule bit for bit: every element is
