@@ -3,8 +3,11 @@
 //!
 //! Lives at src/solvers/interior_point/hip_solver.rs in the reference tree; `mod.rs` gains
 //!     #[cfg(feature = "hip")] mod hip_solver;
-//! and the existing `impl<F: Float> Solver<F> for InteriorPoint<F>` (mod.rs:161-169) is gated with
-//! `#[cfg(not(feature = "hip"))]` for F = f64.
+//! and, under `feature = "hip"`, the generic `impl<F: Float> Solver<F> for InteriorPoint<F>` (mod.rs:161-169) is
+//! REPLACED BY TWO CONCRETE IMPLS (a `cfg` cannot remove one instantiation of a generic impl, and a generic impl
+//! beside a concrete one is E0119): `impl Solver<f32> for InteriorPoint<f32>` calling the unchanged CPU body, which
+//! moves into the inherent method `InteriorPoint::<F>::solve_cpu`, and the `impl Solver<f64> for InteriorPoint<f64>`
+//! below.  The exact edit: ../interior_point_mod.rs.patch.
 #![allow(unsafe_code)]
 
 use ndarray::Array1;

@@ -38,17 +38,22 @@ class _DevPtr:
 class TorchCollective:
     """lpipm_allreduce_fn over a torch.distributed process group.
 
-    on_stream (default: True for the "nccl" backend = RCCL): the library does not drain its stream before calling
-    (lpipm_set_collective_on_stream); the all-reduce is issued with the SOLVER's stream as torch's current stream, so
-    RCCL orders it behind the kernels that produced the operand and the kernels that follow wait for it on the device
-    -- the host never blocks.  Otherwise (gloo: the copy through the host is synchronous anyway) the drained contract."""
+    Default: the DRAINED contract (the library drains its stream, the callback returns with the result in place).
+    on_stream=True (or LPIPM_COLLECTIVE_ON_STREAM=1 in the environment): the library does not drain its stream before
+    calling (lpipm_set_collective_on_stream); the all-reduce is issued with the SOLVER's stream as torch's current stream,
+    so RCCL orders it behind the kernels that produced the operand and the kernels that follow wait for it on the device
+    -- the host never blocks.  OPT-IN because it has so far only been exercised with gloo ranks (where the callback
+    synchronises the stream itself) and with ONE RCCL rank; no run with >= 2 RCCL ranks has been recorded
+    (INTEGRATION.md)."""
 
     def __init__(self, device: int, group=None, on_stream=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group, self.device = torch, dist, group, int(device)
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
-        self.on_stream = (backend == "nccl") if on_stream is None else bool(on_stream)
+        import os
+        env = os.environ.get("LPIPM_COLLECTIVE_ON_STREAM") == "1"
+        self.on_stream = (backend == "nccl" and env) if on_stream is None else bool(on_stream)
         self.calls = 0
         self.bytes = 0
         self.error = None

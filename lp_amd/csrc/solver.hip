@@ -67,7 +67,7 @@ struct lpipm_ctx {
     hipEvent_t ev_fork = nullptr;
     PotrfLookahead la;                   // trailing updates of one factorisation beside the next panel's chain (launch_potrf)
     std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
-    int refine = -1;             // -1: decide from the environment at first use.  0 (default): plain solves; LPIPM_REFINE=2: every
+    int refine = 0;              // set from the environment by lpipm_create.  0 (default): plain solves; LPIPM_REFINE=2: every
                                  //   solve of every iteration refined; =1: only from mu / mu_0 <= refine_below() on.
                                  //   Built because ~1 % of the C4 members took a poor last step (alpha 0.987 for 0.99995) and
                                  //   one iteration more than the oracle; measured on all 256 members, no mode removes such
@@ -275,6 +275,9 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
         return LPIPM_ERR_HIP;
     }
     c->status_cap = 1;
+    // LPIPM_REFINE (see lpipm_ctx::refine) is read ONCE, here: the arena layout depends on it (M0, R0, Rho and the symv slabs
+    // exist only for a refining context: 134 MB at C3, 2 GB at m = 16384, per member of a lockstep batch)
+    { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     // Two CU-masked streams for the factorisation that runs beside A.D.A^T (enqueue_factor_overlapped).  Mask bit i is
     // CU i/8 of XCC i%8 (scripts/diag/cu_mask_probe.cpp; an XCC with no bit set would be unrestricted): the chain stream
     // gets CUs 0..R-1 of every XCC, the throughput stream the rest.  OFF by default -- measured at C3 the scheme is
@@ -430,7 +433,12 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.p = ar.take<double>(np); v.u = ar.take<double>(np); v.dx = ar.take<double>(np); v.dz = ar.take<double>(np);
     v.dxdz = ar.take<double>(np);
     v.rP = ar.take<double>(mp); v.rP2 = ar.take<double>(mp); v.q = ar.take<double>(mp); v.dy = ar.take<double>(mp);
-    v.Ax = ar.take<double>(mp * (size_t)gemv_dual_chunks((int)np));
+    // chunk slabs of A.x: sized by the count the launches use (the STORED columns npa -- gemv_dual_chunks is not monotone:
+    // 256-column chunks below 4096 columns, 1024-column chunks from there on, so np's count can be the smaller one)
+    {
+        const int ch_a = gemv_dual_chunks(c->npa), ch_n = gemv_dual_chunks((int)np);
+        v.Ax = ar.take<double>(mp * (size_t)(ch_a > ch_n ? ch_a : ch_n));
+    }
     v.W = ar.take<double>(2 * np); v.R = ar.take<double>(2 * mp);
     c->Y = ar.take<double>(2 * mp);
     c->ATpart = ar.take<double>((size_t)c->nsplit * 2 * np);
@@ -441,9 +449,12 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     v.skip_refine = ar.take<int>(1);
     c->M = ar.take<double>(mp * mp);
     LP_HIP(factor_plan_create(c->plan, c->M, c->mp, c->mp, ar, build, c->st, super_for(c->mp), merge_edge_for(c->B)));
-    c->M0 = ar.take<double>(mp * mp);
-    c->R0 = ar.take<double>(2 * mp); c->Rho = ar.take<double>(2 * mp);
-    c->symv_ws = ar.take<double>(symv_slab_doubles(c->mp));
+    c->M0 = c->R0 = c->Rho = c->symv_ws = nullptr;
+    if (c->refine > 0) {     // only the refined solves read the matrix itself
+        c->M0 = ar.take<double>(mp * mp);
+        c->R0 = ar.take<double>(2 * mp); c->Rho = ar.take<double>(2 * mp);
+        c->symv_ws = ar.take<double>(symv_slab_doubles(c->mp));
+    }
     c->tau = ar.take<double>(mp);
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
@@ -935,7 +946,6 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         printf("alpha     \trho_p     \trho_d     \trho_g     \trho_mu    \tobj       \n");
         print_row(1.0, *c->status_host);
     }
-    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     c->refine_now = c->refine == 2 || (c->refine == 1 && c->status_host->rho_mu <= refine_below());
     int ip = o->ip ? 1 : 0;
     int ret = LPIPM_ITERATION_LIMIT;
@@ -1042,27 +1052,39 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
     if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
     if (o->solver_type != LPIPM_SOLVER_CHOLESKY) return LPIPM_ERR_UNSUPPORTED;      // the QR arms are single-LP
     if (!c->has_problem) return LPIPM_ERR_NO_PROBLEM;
-    if (c->colsplit || c->profiling) return LPIPM_ERR_UNSUPPORTED;
+    if (c->colsplit) return LPIPM_ERR_UNSUPPORTED;
     LP_HIP(hipSetDevice(c->device));
     const int B = c->B;
     VecArgs& v = c->va;
     hipStream_t st = c->st;
     c->factor_in_head = false;
+    // profiling (lpipm_set_profiling): the same event marks as a single solve; a phase's time is that of the whole batch's launch
+    for (int t = 0; t < T_NTAGS; ++t) c->tag_ms[t] = 0.0;
+    c->times = lpipm_phase_times{};
+    c->nmarks = 0;
+    c->gemv_passes = 0;
+    uint64_t batch_iterations = 0;
+    if (c->profiling) LP_HIP(hipEventRecord(c->ev_begin, st));
     vec_blind_start(v, st);                                                  // feasible_point.rs:24-31
+    prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));                  // feasible_point.rs:32, mod.rs:206
+    prof_mark(c, T_VEC);
     LP_HIP(hipStreamSynchronize(st));
+    prof_collect(c);
     std::vector<int> ret((size_t)B, -1);                                     // -1: still iterating
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
     bool head_out = false;
-    if (c->refine < 0) { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     c->refine_now = c->refine == 2;      // (selective mode) at the starting point mu / mu_0 = 1: no member refines its first iteration
     for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
         if (!head_out) LP_TRY(enqueue_head(c));
         LP_TRY(enqueue_tail(c, ip, o));
+        const size_t marks = c->nmarks;
         head_out = iteration < o->max_iter;
         if (head_out) LP_TRY(enqueue_head(c));       // next iteration's A.D.A^T, before this one's status is read
         LP_HIP(hipEventSynchronize(c->ev_status));
+        prof_collect(c, marks);
+        ++batch_iterations;
         ip = 0;                                                              // mod.rs:223
         for (int i = 0; i < B; ++i) {
             if (ret[i] >= 0) continue;
@@ -1090,7 +1112,18 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
         if (xo.dev) LP_HIP(hipMemcpyAsync(xo.dev + row * xo.stride_bytes, src, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
         else if (xo.host[row]) LP_HIP(hipMemcpyAsync(xo.host[row], src, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
     LP_HIP(hipStreamSynchronize(st));
+    if (c->profiling) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev_begin, c->ev_end);
+        c->times.total_ms = ms;
+        c->times.adat_ms = c->tag_ms[T_ADAT]; c->times.potrf_ms = c->tag_ms[T_POTRF];
+        c->times.trsv_ms = c->tag_ms[T_TRSV]; c->times.gemv_ms = c->tag_ms[T_GEMV]; c->times.vec_ms = c->tag_ms[T_VEC];
+        c->times.adat_launches = batch_iterations;     // launches of the batched kernel (each covers all B members)
+        c->times.iterations = batch_iterations;        // lockstep iterations of the batch (= the slowest member's count)
+        c->times.gemv_passes = c->gemv_passes;
+    }
     for (int i = 0; i < B; ++i) {
         status_out[i] = ret[i];
         const bool has_x = ret[i] == LPIPM_OK || ret[i] == LPIPM_ITERATION_LIMIT;
@@ -1115,6 +1148,23 @@ extern "C" int lpipm_solve_lockstep_device(lpipm_ctx* c, const lpipm_opts* o, vo
     if (!c || !x_dev_out || row_stride < c->n) return LPIPM_ERR_BAD_ARGUMENT;
     XOut xo; xo.dev = (char*)x_dev_out; xo.stride_bytes = row_stride * sizeof(double);
     return solve_lockstep(c, o, xo, nullptr, fun_out, iterations_out, status_out);
+}
+
+// Bytes one member of a lockstep batch of this shape occupies: the real layout (a measuring pass of layout_problem on a
+// scratch context carrying only the geometry), not a formula that drifts from it.
+static size_t lockstep_bytes_per_lp(const lpipm_ctx* c, uint64_t m, uint64_t n) {
+    lpipm_ctx t;
+    t.num_cu = c->num_cu; t.refine = c->refine; t.B = 32;
+    t.mp = (int)round_up(m, NB); t.np = (int)round_up(n, BK); t.npa = t.np;
+    t.nsplit = t.mp / GEMVT_ROWS;
+    const int nt = t.mp / TILE;
+    t.ntiles = nt * (nt + 1) / 2;
+    t.adat_nwg = 2 * t.num_cu / t.B < 1 ? 1 : 2 * t.num_cu / t.B;
+    if (t.adat_nwg > t.ntiles) t.adat_nwg = t.ntiles;
+    t.ws_slabs = gemm_streamk_slabs(t.ntiles, t.npa / BK, t.adat_nwg);
+    Arena measure;
+    if (layout_problem(&t, measure, false) != LPIPM_OK) return (size_t)-1;
+    return (size_t)round_up(measure.off, 4096);
 }
 
 // A shard of independent LPs on one device.
@@ -1147,8 +1197,7 @@ static int batch_impl(lpipm_ctx* c, uint64_t count, const uint64_t* m, const uin
             size_t free_b = 0, total_b = 0;
             LP_HIP(hipMemGetInfo(&free_b, &total_b));
             free_b += c->arena_bytes;                // the current arena is released before the next one is made
-            const double mp = (double)round_up(m[i], NB), np = (double)round_up(n[i], BK);
-            const double per_lp = 8.0 * (mp * np + 4.5 * mp * mp + 16.0 * np + 2.0 * TILE * TILE * 8.0) + (1 << 20);
+            const double per_lp = (double)lockstep_bytes_per_lp(c, m[i], n[i]);     // the real arena layout of one member
             size_t chunk;
             if (c->lockstep_max > 0) chunk = (size_t)c->lockstep_max;
             else if (grp.size() > 32) chunk = 32;
@@ -1477,23 +1526,26 @@ extern "C" int lpipm_k_chol_solve(lpipm_ctx* c, uint64_t m, int nrhs, const doub
 
 extern "C" int lpipm_k_symv_residual(lpipm_ctx* c, uint64_t m, const double* M, int nrhs, const double* V, const double* R0,
                                      double* Rho) {
-    if (!c || !M || !V || !R0 || !Rho || m == 0 || m > (1u << 20) || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
+    if (!c || !M || !V || !R0 || !Rho || m == 0 || m > 16384 || (nrhs != 1 && nrhs != 2)) return LPIPM_ERR_BAD_ARGUMENT;
     LP_HIP(hipSetDevice(c->device));
     const int mp = (int)round_up(m, NB);
     LP_TRY(kbuf_ensure(c, mp));
     double *ws = nullptr, *vbuf = nullptr;
-    LP_HIP(hipMalloc((void**)&ws, symv_slab_doubles(mp) * sizeof(double)));
-    LP_HIP(hipMalloc((void**)&vbuf, (size_t)6 * mp * sizeof(double)));
-    LP_HIP(hipMemsetAsync(vbuf, 0, (size_t)6 * mp * sizeof(double), c->st));
-    LP_HIP(hipMemsetAsync(c->kM0, 0, (size_t)mp * mp * sizeof(double), c->st));
-    LP_HIP(hipMemcpy2DAsync(c->kM0, (size_t)mp * sizeof(double), M, m * sizeof(double), m * sizeof(double), m, hipMemcpyHostToDevice, c->st));
-    LP_HIP(hipMemcpy2DAsync(vbuf, (size_t)mp * sizeof(double), V, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st));
-    LP_HIP(hipMemcpy2DAsync(vbuf + 2 * mp, (size_t)mp * sizeof(double), R0, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st));
-    hipError_t e = launch_symv_residual(c->kM0, mp, mp, nrhs, vbuf, mp, vbuf + 2 * mp, mp, vbuf + 4 * mp, mp, ws, c->st);
+    // every failure leaves through the one exit below, which frees both buffers
+    hipError_t e = hipMalloc((void**)&ws, symv_slab_doubles(mp) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&vbuf, (size_t)6 * mp * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(vbuf, 0, (size_t)6 * mp * sizeof(double), c->st);
+    if (e == hipSuccess) e = hipMemsetAsync(c->kM0, 0, (size_t)mp * mp * sizeof(double), c->st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(c->kM0, (size_t)mp * sizeof(double), M, m * sizeof(double), m * sizeof(double), m, hipMemcpyHostToDevice, c->st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(vbuf, (size_t)mp * sizeof(double), V, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(vbuf + 2 * mp, (size_t)mp * sizeof(double), R0, m * sizeof(double), m * sizeof(double), nrhs, hipMemcpyHostToDevice, c->st);
+    if (e == hipSuccess) e = launch_symv_residual(c->kM0, mp, mp, nrhs, vbuf, mp, vbuf + 2 * mp, mp, vbuf + 4 * mp, mp, ws, c->st);
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(Rho, m * sizeof(double), vbuf + 4 * mp, (size_t)mp * sizeof(double), m * sizeof(double), nrhs, hipMemcpyDeviceToHost, c->st);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
-    (void)hipFree(ws); (void)hipFree(vbuf);
+    const hipError_t es = hipStreamSynchronize(c->st);      // also on failure: nothing may still use the buffers freed next
+    if (e == hipSuccess) e = es;
+    if (ws) (void)hipFree(ws);
+    if (vbuf) (void)hipFree(vbuf);
     LP_HIP(e);
     return LPIPM_OK;
 }
@@ -1578,7 +1630,6 @@ extern "C" int lpipm_k_iteration(lpipm_ctx* c, const lpipm_opts* o, int ip, doub
     LP_HIP(hipSetDevice(c->device));
     VecArgs& v = c->va;
     hipStream_t st = c->st;
-    if (c->refine < 0) c->refine = 0;
     c->refine_now = c->refine == 2;
     c->factor_in_head = false;
     vec_blind_start(v, st);                                   // clears done / flags; the iterate is overwritten next

@@ -16,7 +16,7 @@ enum {
 };
 enum { ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_UNBOUNDED = 2, ST_UNFINISHED = 3 };  // indicators.rs:85-90
 enum { FLAG_NAN_PQ = 1 };
-// Selective refinement (LPIPM_REFINE=1, a measurement mode; the default refines every solve): the Cholesky solves of an
+// Selective refinement (LPIPM_REFINE=1, a measurement mode; the default, LPIPM_REFINE unset, refines nothing; =2 refines every solve): the Cholesky solves of an
 // iteration are refined when mu / mu_0 of the point the normal equations are formed at is at most this.  The decision is
 // the LP's own (device word skip_refine, mirrored by the host from the status record): the same alone and in a batch.
 constexpr double REFINE_BELOW_RHO_MU = 1e-2;
