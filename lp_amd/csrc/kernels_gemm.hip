@@ -234,6 +234,21 @@ __device__ __forceinline__ double buf_load_d(__amdgpu_buffer_rsrc_t r, unsigned 
 __device__ __forceinline__ void buf_store_d(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)voff, (int)soff, 0);
 }
+// the same with a cache-policy operand (16 = sc1: write-through / L1-bypassing, see the units kernel).  The value goes
+// through a by-value double: a bit_cast written directly on `acc[mi][nj][r]` inside the unrolled loops stored element 0
+// of the accumulator quad for every r (hipcc 7.2, seen on the GPU: rows fq + 4r, r > 0, received row fq's values).
+template <int AUX>
+__device__ __forceinline__ void buf_store_d_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)voff, (int)soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store_d2_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, d2 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)voff, (int)soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ d2 buf_load_d2_aux(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
 
 // One pass over the k-tiles [kb, ke) of a tile, in chunks that end at multiples of kc k-tiles (kc == 0: one chunk).
 // The software pipeline (next k-tile prefetched into registers while the current one is multiplied out of LDS) runs
@@ -447,6 +462,192 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         buf_store_d(wr_, offW, (unsigned)(((mi * 16 + 4 * r) * TILE + nj * 16) * sizeof(double)), acc[mi][nj][r]);
         }, [](bool, unsigned&, unsigned&) {});
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A.D.A^T as (tile, chunk) units with an in-launch combine (AdatUnitsArgs, lpipm_internal.hpp).
+// Hand-off protocol (MI355X_MICROARCH.md, Workgroup dispatch / inter-workgroup visibility; cdna_hip_programming.md
+// Guideline 16 in its counter form): per-XCD L2s are not coherent, so
+//   producer : slab stores are WRITE-THROUGH (sc1) -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier ->
+//              ONE lane adds to the tile's counter (relaxed, agent scope);
+//   consumer : the workgroup whose add completed the tile (told by the value the add returned) -> that lane's
+//              agent-scope acquire + s_waitcnt vmcnt(0) -> workgroup barrier -> EVERY load of the slabs is an sc1 load.
+// The finished tile of M is stored write-through as well when group words are signalled: its readers are other
+// kernels (the factorisation's chain, on another stream) that start while this launch is still running -- their
+// kernel-start acquire drops stale lines, but nothing would write this XCD's dirty lines back before this launch ends.
+constexpr int AUX_SC1 = 16;
+struct UnitsK {
+    const double* A; long long lda;
+    const double* s;
+    double* C; long long ldc;
+    double* C2;
+    int KT, kc, cpt;
+    int ntiles;
+    const int2* tile_list;
+    const int2* unit_list;
+    int nunits, upc, window;
+    int diag_pad_from;
+    double* slabs;
+    unsigned int* tile_cnt;
+    unsigned int* grp_cnt;
+    int grp_w;
+    BatchK bk;
+};
+// Workgroups are dispatched in index order and dealt to the 8 XCDs round-robin: inside a window of `w` consecutive
+// indices (the workgroups resident together) XCD x gets the contiguous logical range [x*w/8, (x+1)*w/8) -- consecutive
+// units of the list (same k-range, neighbouring tiles) share one L2.
+__device__ __forceinline__ int window_remap(int b, int w, int n) {
+    const int base = (b / w) * w;
+    const int len = n - base < w ? n - base : w;       // the last window may be short
+    const int r = b - base;
+    const int q = len >> 3, rem = len & 7, x = r & 7;
+    return base + (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (r >> 3);
+}
+
+template <bool GRP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_units_kernel(const UnitsK p0) {
+    if (batch_done(p0.bk)) return;
+    UnitsK p = p0;
+    p.A = batch_ptr(p0.A, p0.bk); p.s = batch_ptr(p0.s, p0.bk); p.C = batch_ptr(p0.C, p0.bk); p.C2 = batch_ptr(p0.C2, p0.bk);
+    p.slabs = batch_ptr(p0.slabs, p0.bk); p.tile_cnt = batch_ptr(p0.tile_cnt, p0.bk); p.grp_cnt = batch_ptr(p0.grp_cnt, p0.bk);
+    __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
+    __shared__ unsigned int s_old;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves: 64 rows x 32 columns each
+    const int fr = lane & 15, fq = lane >> 4;
+    const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
+    const int b = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
+    const int2 un = p.unit_list[p.bk.xcd_major ? b : window_remap(b, p.window, p.nunits)];   // xcd-major: one LP per XCD anyway
+    const int tile = un.x, q0 = un.y;
+    const int q1 = q0 + p.upc < p.cpt ? q0 + p.upc : p.cpt;
+    const int2 tc = p.tile_list[tile];
+    const int ti = tc.x, tj = tc.y;
+    const int KT = p.KT;
+    const unsigned rowA = (unsigned)(p.lda * (long long)sizeof(double));
+    const unsigned offP = (unsigned)srow * rowA + (unsigned)(scol * sizeof(double));
+    const unsigned offS = (unsigned)(scol * sizeof(double));
+    const unsigned p64 = 64u * rowA;
+    const __amdgpu_buffer_rsrc_t Pr = make_rsrc(p.A + (long long)(ti * TILE) * p.lda, (unsigned)TILE * rowA);
+    const __amdgpu_buffer_rsrc_t Qr = make_rsrc(p.A + (long long)(tj * TILE) * p.lda, (unsigned)TILE * rowA);
+    const __amdgpu_buffer_rsrc_t Sr = make_rsrc(p.s, (unsigned)KT * (unsigned)(BK * sizeof(double)));
+    // this tile's slabs as ONE buffer: slab q at byte q * 128 KiB
+    constexpr unsigned SLAB_BYTES = (unsigned)(TILE * TILE * sizeof(double));
+    const __amdgpu_buffer_rsrc_t Wr = make_rsrc(p.slabs + (long long)tile * p.cpt * (TILE * TILE), (unsigned)p.cpt * SLAB_BYTES);
+    d4 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int kb = q0 * p.kc, ke = q1 * p.kc < KT ? q1 * p.kc : KT;
+    if (p.cpt == 1) {
+        // a contraction of one chunk: the unit is the whole tile, stored directly
+        tile_pass_w8<true>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq, 0,
+                           [&](bool, bool) {}, [](bool, unsigned&, unsigned&) {});
+        const unsigned rowC = (unsigned)(p.ldc * (long long)sizeof(double));
+        const unsigned offC = (unsigned)(wr * 64 + fq) * rowC + (unsigned)((wc * 32 + fr) * sizeof(double));
+        const __amdgpu_buffer_rsrc_t cr = make_rsrc(p.C + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
+        const __amdgpu_buffer_rsrc_t cr2 = make_rsrc((p.C2 ? p.C2 : p.C) + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
+        const bool pad = p.diag_pad_from >= 0 && ti == tj;
+        const int row0 = ti * TILE + wr * 64 + fq, dd = wc * 32 - wr * 64;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    double v = acc[mi][nj][r];
+                    if (pad && (mi - nj) * 16 + fq + 4 * r - fr == dd && row0 + mi * 16 + 4 * r >= p.diag_pad_from) v = 1.0;
+                    const unsigned so = (unsigned)(mi * 16 + 4 * r) * rowC + nj * 128;
+                    buf_store_d_aux<GRP ? AUX_SC1 : 0>(cr, offC, so, v);
+                    if (p.C2) buf_store_d_aux<0>(cr2, offC, so, v);
+                }
+    } else {
+        int q = q0;
+        const unsigned offW = (unsigned)(((wr * 64 + fq) * TILE + wc * 32 + fr) * sizeof(double));
+        tile_pass_w8<true>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq, p.kc,
+                           [&](bool, bool) {
+                               const unsigned sb = (unsigned)q * SLAB_BYTES;
+#pragma unroll
+                               for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                                   for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                       for (int nj = 0; nj < 2; ++nj)
+                                           buf_store_d_aux<AUX_SC1>(Wr, offW, sb + (unsigned)(((mi * 16 + 4 * r) * TILE + nj * 16) * sizeof(double)),
+                                                                    acc[mi][nj][r]);
+                               ++q;
+                           },
+                           [](bool, unsigned&, unsigned&) {});
+        // publish: every storing wave drains its stores, then ONE lane adds this unit's chunks to the tile's counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_old = __hip_atomic_fetch_add(p.tile_cnt + tile, (unsigned)(q1 - q0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((int)s_old + (q1 - q0) != p.cpt) return;           // not the last arriver of this tile (workgroup-uniform)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // combine: slabs 0 .. cpt-1 added in chunk order; a thread owns 16 pairs of adjacent elements, 1024 elements apart
+        const unsigned rowC = (unsigned)(p.ldc * (long long)sizeof(double));
+        const __amdgpu_buffer_rsrc_t cr = make_rsrc(p.C + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
+        const __amdgpu_buffer_rsrc_t cr2 = make_rsrc((p.C2 ? p.C2 : p.C) + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
+        const unsigned voff = (unsigned)tid * 16u;
+        const int cpt = p.cpt;
+        for (int i = 0; i < 16; i += 2) {
+            d2 sum[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                sum[a] = buf_load_d2_aux<AUX_SC1>(Wr, voff, (unsigned)(i + a) * 8192u);
+            for (int qb = 1; qb < cpt; qb += 4) {
+                d2 v[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if (qb + j < cpt)
+                            v[a][j] = buf_load_d2_aux<AUX_SC1>(Wr, voff, (unsigned)(qb + j) * SLAB_BYTES + (unsigned)(i + a) * 8192u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if (qb + j < cpt) sum[a] += v[a][j];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int e = tid * 2 + (i + a) * 1024;
+                const int r = e >> 7, c = e & 127;
+                const int row = ti * TILE + r, col = tj * TILE + c;
+                d2 v = sum[a];
+                if (p.diag_pad_from >= 0 && ti == tj) {
+                    if (row == col && row >= p.diag_pad_from) v[0] = 1.0;
+                    if (row == col + 1 && row >= p.diag_pad_from) v[1] = 1.0;
+                }
+                const unsigned co = (unsigned)r * rowC + (unsigned)(c * sizeof(double));
+                buf_store_d2_aux<GRP ? AUX_SC1 : 0>(cr, co, 0u, v);
+                if (p.C2) buf_store_d2_aux<0>(cr2, co, 0u, v);
+            }
+        }
+    }
+    if (GRP) {   // this tile of M is complete: drain its (write-through) stores, then count it in its column group's word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) (void)__hip_atomic_fetch_add(p.grp_cnt + tj / p.grp_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The device-side wait of a stream: see launch_wait_count.
+__global__ __launch_bounds__(64) void wait_count_kernel(const unsigned int* cnt, unsigned int target, const int* done,
+                                                        unsigned int* timeout) {
+    if (threadIdx.x != 0) return;
+    if (done && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // the producer returned at once
+    for (unsigned int spins = 0; spins < (1u << 21); ++spins) {        // ~1 us per poll: gives up after a few seconds
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One full tile per workgroup (Cholesky trailing update, TRSM-as-GEMM): no k-split, no slabs.
@@ -770,6 +971,38 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
         e = hipGetLastError();
     }
     return e;
+}
+
+int adat_units_cpt(int K) {
+    const int KT = K / BK, kc = gemm_streamk_chunk(KT);
+    return KT <= kc ? 1 : (KT + kc - 1) / kc;
+}
+
+hipError_t launch_adat_units(const AdatUnitsArgs& a, hipStream_t st) {
+    if (a.ntiles <= 0 || a.nunits <= 0 || a.K <= 0) return hipSuccess;
+    if (a.lda >= (1 << 22) || a.ldc >= (1 << 22)) return hipErrorInvalidValue;   // 128-row panels are 32-bit buffers
+    if (!a.A || !a.s || !a.C || !a.tile_list || !a.unit_list || a.upc < 1 || a.window < 8 || a.window % 8) return hipErrorInvalidValue;
+    UnitsK k{};
+    k.A = a.A; k.lda = a.lda; k.s = a.s; k.C = a.C; k.ldc = a.ldc; k.C2 = a.C2;
+    k.KT = a.K / BK; k.kc = gemm_streamk_chunk(k.KT); k.cpt = adat_units_cpt(a.K);
+    if (k.cpt == 1) k.kc = 0;
+    if (k.cpt > 1 && (!a.slabs || !a.tile_cnt)) return hipErrorInvalidValue;
+    if (k.cpt > 256) return hipErrorInvalidValue;          // a tile's slabs are one 32-bit buffer
+    k.ntiles = a.ntiles; k.tile_list = a.tile_list; k.unit_list = a.unit_list; k.nunits = a.nunits; k.upc = a.upc;
+    k.window = a.window; k.diag_pad_from = a.diag_pad_from; k.slabs = a.slabs; k.tile_cnt = a.tile_cnt;
+    k.grp_cnt = a.grp_cnt; k.grp_w = a.grp_w > 0 ? a.grp_w : 1; k.bk = batch_k(a.batch);
+    const int B = a.batch.count;
+    const bool xm = B >= 8 && B % 8 == 0;                  // one LP per XCD at a time (see BatchK)
+    k.bk.xcd_major = xm ? 1 : 0;
+    const dim3 grid = xm ? dim3(8, a.nunits, B / 8) : dim3(a.nunits, 1, B);
+    if (a.grp_cnt) hipLaunchKernelGGL(gemm_nt_units_kernel<true>, grid, dim3(512), 0, st, k);
+    else           hipLaunchKernelGGL(gemm_nt_units_kernel<false>, grid, dim3(512), 0, st, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_wait_count(const unsigned int* cnt, unsigned int target, const int* done, unsigned int* timeout, hipStream_t st) {
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, st, cnt, target, done, timeout);
+    return hipGetLastError();
 }
 
 hipError_t launch_gemm_grouped(const GemmTileDesc* descs_dev, int ntiles, hipStream_t st, const Batch& bt, int edge) {

@@ -111,6 +111,40 @@ int gemm_streamk_chunk(int KT);
 size_t gemm_streamk_slabs(int ntiles, int KT, int nwg);
 bool gemm_streamk_split(int KT);     // contraction long enough to be cut into chunks (only then can GemmArgs::C2 be used)
 int gemm_streamk_nwg(int ntiles, int KT, int num_cu);
+// ---- A.D.A^T as (tile, chunk) UNITS with an in-launch combine (kernels_gemm.hip, gemm_nt_units_kernel) --------------
+// The contraction of every lower tile is cut into the canonical chunks (gemm_streamk_chunk); a workgroup computes `upc`
+// consecutive chunks of ONE tile, writes each chunk sum to that chunk's slab (write-through stores: nothing to wait for),
+// and adds the number of chunks it did to the tile's arrival counter.  The workgroup whose add completes the tile adds the
+// tile's slabs IN CHUNK ORDER and stores the tile -- the same sums in the same order as a single running pass that flushes
+// at every chunk boundary, whatever the decomposition (no separate fix-up launch; the bits of M do not depend on the
+// workgroup count, on `upc`, or on who arrives last).  A non-persistent grid, one unit per workgroup, dispatched in list
+// order: with a column-group-major list the groups of M complete one after the other WHILE the launch runs, and the
+// workgroup that completes a group's last tile bumps that group's word -- what the factorisation's chain waits for
+// (solver.hip, enqueue_factor_grouped).
+struct AdatUnitsArgs {
+    const double* A; int64_t lda;     // P = Q = A
+    const double* s;                  // dinv (per-k scale)
+    double* C; int64_t ldc;           // M
+    double* C2;                       // nullable second copy
+    int K;                            // columns (multiple of BK)
+    int ntiles;
+    const int2* tile_list;            // (ti, tj) per tile, device
+    const int2* unit_list;            // (tile index, first chunk) per unit in dispatch order, device
+    int nunits, upc;
+    int window;                       // workgroups resident together (slots), multiple of 8: XCD-aware renumbering inside windows
+    int diag_pad_from;
+    double* slabs;                    // ntiles * cpt slabs of TILE*TILE doubles
+    unsigned int* tile_cnt;           // ntiles arrival counters, ZEROED before the launch (by the caller, in stream order)
+    unsigned int* grp_cnt;            // nullable: completed tiles per column group (tj / grp_w), zeroed likewise
+    int grp_w;
+    Batch batch;
+};
+int adat_units_cpt(int K);            // chunks per tile for a contraction of K columns
+hipError_t launch_adat_units(const AdatUnitsArgs& a, hipStream_t st);
+// One wave that returns when *cnt >= target (or when *done != 0, or after a bounded number of polls, which sets *timeout):
+// the device-side wait of a stream for a group word of a running launch on another stream.
+hipError_t launch_wait_count(const unsigned int* cnt, unsigned int target, const int* done, unsigned int* timeout, hipStream_t st);
+
 // One output tile (128x128, or 64x64 with edge = 64) of a grouped launch: C = alpha * P[0:E, kb:ke) . Q[0:E, kb:ke)^T
 // (k-range in units of BK), each tile with its own operands.
 struct GemmTileDesc {

@@ -57,8 +57,24 @@ struct lpipm_ctx {
     double *tau = nullptr, *ktau = nullptr;   // Householder scalars of the QR arms
     double *A = nullptr, *M = nullptr, *ws = nullptr, *Y = nullptr, *ATpart = nullptr, *xout = nullptr;
     double *M0 = nullptr, *R0 = nullptr, *Rho = nullptr, *symv_ws = nullptr;   // refinement of the Cholesky solve
-    // factorisation beside A.D.A^T (enqueue_factor_overlapped): two CU-masked streams, column groups of the tile list
-    hipStream_t st_a = nullptr, st_b = nullptr;
+    // A.D.A^T as (tile, chunk) units with an in-launch combine (launch_adat_units; kernels_gemm.hip)
+    int units_env = 1;                   // LPIPM_ADAT_UNITS=0: the round-2 kernel (data-parallel tiles + stream-K + fix-up launch)
+    bool units = false;                  // this problem runs the units kernel (geometry: the slabs fit the budget)
+    int cpt = 1, upc = 1;                // chunks per tile, chunks per unit
+    int nunits = 0, nunits_grp = 0, window = 512;
+    int2* unit_list = nullptr;           // (tile, first chunk) in dispatch order: chunk-major over the XCD-aware tile order
+    int2* unit_list_grp = nullptr;       // column-group-major (tile indices into tile_list_grp): groups complete one after the other
+    unsigned int* tile_cnt = nullptr;    // arena: arrival counters of the tiles, then the group words (one memset clears both)
+    unsigned int* grp_cnt = nullptr;
+    size_t cnt_bytes = 0;
+    unsigned int* wait_timeout = nullptr;   // arena: set by a wait kernel that gave up (a producer that never ran)
+    unsigned int* timeout_host = nullptr;   // pinned mirror, read with the status record
+    // factorisation beside A.D.A^T (enqueue_factor_grouped): CU-masked streams, column groups of the tile list
+    hipStream_t st_a = nullptr, st_b = nullptr, st_u = nullptr;
+    double* ws_upd = nullptr;            // stream-K slabs of the left-looking updates (they run beside A.D.A^T: own buffer)
+    size_t ws_upd_slabs = 0;
+    unsigned int* sk_claim_upd = nullptr;
+    hipEvent_t ev_adat_done = nullptr;
     int overlap_cus = 0;                 // CUs per XCC reserved for the chain stream (0: no masked streams)
     bool overlap = false;                // this problem can be factorised beside its A.D.A^T (geometry)
     bool factor_in_head = false;         // ... and the current solve does so (Cholesky arm, no column split, no graph replay)
@@ -116,6 +132,9 @@ struct lpipm_ctx {
     double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
     size_t mpack_count = 0;
 };
+
+// The factorisation beside A.D.A^T (enqueue_factor_grouped) unless LPIPM_OVERLAP says otherwise: see lpipm_create.
+constexpr bool OVERLAP_DEFAULT = false;
 
 static void drop_graphs(lpipm_ctx* c) {
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -187,14 +206,12 @@ static void prof_collect(lpipm_ctx* c, size_t upto = (size_t)-1) {
     c->nmarks -= upto;
 }
 
-// A.D.A^T time of one completed overlapped section (its events have completed): sum over the column groups
+// A.D.A^T time of one completed side-by-side section (its events have completed): the one launch on the throughput stream
 static void prof_collect_overlap(lpipm_ctx* c, uint64_t section) {
     if (!c->profiling || !c->factor_in_head) return;
     hipEvent_t* ev = c->ev_adat.data() + (section & 1) * 2;
-    for (size_t g = 0; g < c->grp_nt.size(); ++g) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev[4 * g], ev[4 * g + 1]) == hipSuccess) c->tag_ms[T_ADAT] += ms;
-    }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->tag_ms[T_ADAT] += ms;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,29 +295,39 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     // LPIPM_REFINE (see lpipm_ctx::refine) is read ONCE, here: the arena layout depends on it (M0, R0, Rho and the symv slabs
     // exist only for a refining context: 134 MB at C3, 2 GB at m = 16384, per member of a lockstep batch)
     { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
-    // Two CU-masked streams for the factorisation that runs beside A.D.A^T (enqueue_factor_overlapped).  Mask bit i is
-    // CU i/8 of XCC i%8 (scripts/diag/cu_mask_probe.cpp; an XCC with no bit set would be unrestricted): the chain stream
-    // gets CUs 0..R-1 of every XCC, the throughput stream the rest.  OFF by default -- measured at C3 the scheme is
-    // correct but not faster (163 vs 175 it/s; A.D.A^T in eight stream-K pieces on 224 CUs costs what the
-    // hidden chain saves): LPIPM_OVERLAP=1 switches it on, LPIPM_OVERLAP_CUS=R sets R (default 4).  Only on the
+    { const char* e = getenv("LPIPM_ADAT_UNITS"); c->units_env = (e && e[0] == '0') ? 0 : 1; }
+    if (hipHostMalloc((void**)&c->timeout_host, sizeof(unsigned int)) != hipSuccess) {
+        g_err_detail = "failed to allocate the pinned time-out word";
+        lpipm_destroy(c);
+        return LPIPM_ERR_HIP;
+    }
+    *c->timeout_host = 0;
+    // CU-masked streams for the factorisation that runs beside A.D.A^T (enqueue_factor_grouped).  Mask bit i is CU i/8 of
+    // XCC i%8 (scripts/diag/cu_mask_probe.cpp; an XCC with no bit set would be unrestricted): the chain stream (st_b) gets
+    // CUs 0..R-1 of every XCC -- a diagonal-block kernel needs a whole CU's LDS, and on a chip full of A.D.A^T workgroups it
+    // would wait for one --, the throughput streams (st_a: the one A.D.A^T launch; st_u: the left-looking updates that run
+    // beside it) the rest.  LPIPM_OVERLAP=0 switches the scheme off, LPIPM_OVERLAP_CUS=R sets R (default 4).  Only on the
     // 8 x 32 CU layout it was measured on.
     {
         const char* on = getenv("LPIPM_OVERLAP");
         int R = 4;
         if (const char* e = getenv("LPIPM_OVERLAP_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 16) R = v; }
-        if (on && on[0] == '1' && c->num_cu == 256) {
+        if (OVERLAP_DEFAULT ? !(on && on[0] == '0') : (on && on[0] == '1')) if (c->num_cu == 256 && c->units_env) {
             uint32_t ma[8], mb[8];
             for (int w = 0; w < 8; ++w) { ma[w] = 0; mb[w] = 0; }
             for (int i = 0; i < 256; ++i) ((i / 8) < R ? mb : ma)[i / 32] |= 1u << (i % 32);
             if (hipExtStreamCreateWithCUMask(&c->st_a, 8, ma) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&c->st_u, 8, ma) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&c->st_b, 8, mb) == hipSuccess &&
-                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess) {
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&c->ev_adat_done, hipEventDisableTiming) == hipSuccess) {
                 c->overlap_cus = R;
             } else {
                 (void)hipGetLastError();
                 if (c->st_a) (void)hipStreamDestroy(c->st_a);
+                if (c->st_u) (void)hipStreamDestroy(c->st_u);
                 if (c->st_b) (void)hipStreamDestroy(c->st_b);
-                c->st_a = c->st_b = nullptr;
+                c->st_a = c->st_b = c->st_u = nullptr;
             }
         }
     }
@@ -363,7 +390,10 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     for (hipEvent_t e : c->la.ev_chain) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->la.ev_rest) (void)hipEventDestroy(e);
     if (c->st_a) { (void)hipStreamSynchronize(c->st_a); (void)hipStreamDestroy(c->st_a); }
+    if (c->st_u) { (void)hipStreamSynchronize(c->st_u); (void)hipStreamDestroy(c->st_u); }
     if (c->st_b) { (void)hipStreamSynchronize(c->st_b); (void)hipStreamDestroy(c->st_b); }
+    if (c->ev_adat_done) (void)hipEventDestroy(c->ev_adat_done);
+    if (c->timeout_host) (void)hipHostFree(c->timeout_host);
     if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
@@ -421,6 +451,35 @@ static int merge_edge_for(int) {
     return 32;
 }
 
+// How the A.D.A^T launch of this geometry is cut up (a function of mp, npa, the batch count and the CU count alone).
+static void plan_adat(lpipm_ctx* c, int count) {
+    const int nt = c->mp / TILE;
+    c->ntiles = nt * (nt + 1) / 2;
+    // workgroups per LP of the round-2 A.D.A^T launch (LPIPM_ADAT_UNITS=0, and contractions whose slabs would not fit):
+    // stream-K over the chip's share of one LP; a batch that fills the chip with whole tiles needs no k-split
+    if (count == 1) c->adat_nwg = gemm_streamk_nwg(c->ntiles, c->npa / BK, c->num_cu);
+    else if ((long long)count * c->ntiles >= 2LL * c->num_cu) {
+        // more tiles than resident workgroups: each LP gets its share of the 2*CUs slots and stream-K
+        // balances its tiles over them (no tail round of a few leftover tiles)
+        c->adat_nwg = 2 * c->num_cu / count;
+        if (c->adat_nwg < 1) c->adat_nwg = 1;
+        if (c->adat_nwg > c->ntiles) c->adat_nwg = c->ntiles;
+    } else {
+        c->adat_nwg = gemm_streamk_nwg(c->ntiles, c->npa / BK, c->num_cu / count);
+        if (c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
+    }
+    c->ws_slabs = gemm_streamk_slabs(c->ntiles, c->npa / BK, c->adat_nwg);
+    // A.D.A^T as (tile, chunk) units: every chunk sum goes through its own slab (ntiles x cpt slabs of 128 KiB per LP:
+    // 0.55 GB at C3, 38 MB per member at C4) -- up to 4 GiB per LP, beyond that (m = 16384: 34 GB) the round-2 kernel
+    c->cpt = adat_units_cpt(c->npa);
+    c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30);
+    // a single LP: one chunk per unit (parallelism, and column groups that complete while the launch runs); a lockstep
+    // batch fills the chip with whole tiles: one unit = all chunks of a tile, its own workgroup adds its slabs at the end
+    c->upc = count == 1 ? 1 : c->cpt;
+    if (const char* e = getenv("LPIPM_ADAT_UPC")) { const int v = atoi(e); if (v >= 1) c->upc = v < c->cpt ? v : c->cpt; }   // measurement knob
+    if (c->units && c->ws_slabs < (size_t)c->ntiles * c->cpt) c->ws_slabs = (size_t)c->ntiles * c->cpt;
+}
+
 // Per-LP device state: one pass over a measuring arena sizes it, a second pass over the real one places it.
 // Every LP of a lockstep batch gets the same layout, `bstride` bytes after the previous LP's.
 static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
@@ -459,8 +518,17 @@ static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     c->gs = ar.take<double>(8);
     c->xout = ar.take<double>(np);
     c->sk_claim = ar.take<unsigned int>(1);
-    // stream-K chunk slabs of A.D.A^T (tiles that do not divide over the workgroups) and of the factorisation's updates
+    c->sk_claim_upd = ar.take<unsigned int>(1);
+    // arrival counters of the units kernel: one word per tile, then one per column group; cleared by ONE memset per launch
+    // (a block of its own, a multiple of 16 bytes)
+    c->cnt_bytes = (size_t)round_up(((size_t)c->ntiles + 64) * sizeof(unsigned int), 16);
+    c->tile_cnt = (unsigned int*)ar.take<uint4>(c->cnt_bytes / 16);
+    c->grp_cnt = c->tile_cnt + c->ntiles;
+    c->wait_timeout = ar.take<unsigned int>(4);
+    // chunk slabs of A.D.A^T (units kernel: every chunk of every tile; round-2 kernel: the stream-K remainder tiles), and
+    // those of the left-looking updates that run beside it
     c->ws = ar.take<double>(c->ws_slabs * TILE * TILE);
+    c->ws_upd = ar.take<double>(c->ws_upd_slabs * TILE * TILE);
     return LPIPM_OK;
 }
 
@@ -505,47 +573,41 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         if (c->nblk > RED_STRIDE) c->nblk = RED_STRIDE;
         const int nt = mp / TILE;
         std::vector<int2> order = adat_tile_order(nt);
-        c->ntiles = (int)order.size();
-        // workgroups per LP of the A.D.A^T launch: stream-K over the chip's share of one LP; a batch that
-        // fills the chip with whole tiles needs no k-split (and no slabs)
-        if (count == 1) c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu);
-        else if ((long long)count * c->ntiles >= 2LL * c->num_cu) {
-            // more tiles than resident workgroups: each LP gets its share of the 2*CUs slots and stream-K
-            // balances its tiles over them (no tail round of a few leftover tiles)
-            c->adat_nwg = 2 * c->num_cu / count;
-            if (c->adat_nwg < 1) c->adat_nwg = 1;
-            if (c->adat_nwg > c->ntiles) c->adat_nwg = c->ntiles;
-        } else {
-            c->adat_nwg = gemm_streamk_nwg(c->ntiles, npa / BK, c->num_cu / count);
-            if (c->adat_nwg < c->ntiles) c->adat_nwg = c->ntiles;
+        plan_adat(c, count);
+        std::vector<int2> units, units_grp;
+        if (c->units) {
+            for (int q = 0; q < c->cpt; q += c->upc)               // chunk-major: the units resident together are ONE k-range of
+                for (int t = 0; t < c->ntiles; ++t) units.push_back(make_int2(t, q));   // neighbouring tiles (panels shared in L2)
         }
-        c->ws_slabs = gemm_streamk_slabs(c->ntiles, npa / BK, c->adat_nwg);
+        c->nunits = (int)units.size();
+        c->window = 2 * c->num_cu;
         // Factorisation beside A.D.A^T: single LP, big enough that A.D.A^T can hide the factorisation's chain
-        c->overlap = count == 1 && c->st_a != nullptr && mp >= 2048;
+        c->overlap = count == 1 && c->st_a != nullptr && mp >= 2048 && c->units && c->cpt > 1 && nt <= 64 * POTRF_OUTER;
         std::vector<int2> grouped;
+        c->ws_upd_slabs = 0;
         if (c->overlap) {
             grouped = adat_tile_order_grouped(nt, c->grp_off, c->grp_nt);
-            const int wg = 2 * (c->num_cu - 8 * c->overlap_cus);
+            const int wg_cus = c->num_cu - 8 * c->overlap_cus;
             for (size_t g = 0; g < c->grp_nt.size(); ++g) {
-                const size_t s1 = gemm_streamk_slabs(c->grp_nt[g], npa / BK, gemm_streamk_nwg(c->grp_nt[g], npa / BK, wg / 2));
-                const int ku = (int)g * POTRF_OUTER * NB / BK;
-                const size_t s2 = ku ? gemm_streamk_slabs(c->grp_nt[g], ku, gemm_streamk_nwg(c->grp_nt[g], ku, wg / 2)) : 0;
-                if (s1 > c->ws_slabs) c->ws_slabs = s1;
-                if (s2 > c->ws_slabs) c->ws_slabs = s2;
+                for (int q = 0; q < c->cpt; ++q)                   // group-major, chunk-major inside a group
+                    for (int t = 0; t < c->grp_nt[g]; ++t) units_grp.push_back(make_int2(c->grp_off[g] + t, q));
+                const int ku = (int)g * POTRF_OUTER * NB / BK;      // contraction of the left-looking update of group g
+                const size_t s2 = ku ? gemm_streamk_slabs(c->grp_nt[g], ku, gemm_streamk_nwg(c->grp_nt[g], ku, wg_cus)) : 0;
+                if (s2 > c->ws_upd_slabs) c->ws_upd_slabs = s2;
             }
             while (c->ev_ready.size() < c->grp_nt.size()) {
-                hipEvent_t e1, e2, e3, e4;
+                hipEvent_t e1, e2;
                 LP_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
                 LP_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+                c->ev_ready.push_back(e1); c->ev_chain.push_back(e2);
+            }
+            while (c->ev_adat.size() < 4) {     // {begin, end} x 2: the head of iteration k+1 is enqueued before iteration k's times are read
+                hipEvent_t e3;
                 LP_HIP(hipEventCreate(&e3));
-                LP_HIP(hipEventCreate(&e4));
-                c->ev_ready.push_back(e1); c->ev_chain.push_back(e2); c->ev_adat.push_back(e3); c->ev_adat.push_back(e4);
-                hipEvent_t e5, e6;      // second set: the head of iteration k+1 is enqueued before iteration k's times are read
-                LP_HIP(hipEventCreate(&e5));
-                LP_HIP(hipEventCreate(&e6));
-                c->ev_adat.push_back(e5); c->ev_adat.push_back(e6);
+                c->ev_adat.push_back(e3);
             }
         }
+        c->nunits_grp = (int)units_grp.size();
         Arena measure;
         LP_TRY(layout_problem(c, measure, false));
         c->bstride = round_up(measure.off, 4096);
@@ -555,11 +617,17 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         Arena real;
         real.base = c->arena;
         LP_TRY(layout_problem(c, real, true));
-        LP_HIP(hipMalloc((void**)&c->tile_list, (order.size() + grouped.size()) * sizeof(int2)));
+        LP_HIP(hipMalloc((void**)&c->tile_list, (order.size() + grouped.size() + units.size() + units_grp.size() + 1) * sizeof(int2)));
         LP_HIP(hipMemcpyAsync(c->tile_list, order.data(), order.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         c->tile_list_grp = c->tile_list + order.size();
+        c->unit_list = c->tile_list_grp + grouped.size();
+        c->unit_list_grp = c->unit_list + units.size();
         if (!grouped.empty())
             LP_HIP(hipMemcpyAsync(c->tile_list_grp, grouped.data(), grouped.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        if (!units.empty())
+            LP_HIP(hipMemcpyAsync(c->unit_list, units.data(), units.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+        if (!units_grp.empty())
+            LP_HIP(hipMemcpyAsync(c->unit_list_grp, units_grp.data(), units_grp.size() * sizeof(int2), hipMemcpyHostToDevice, st));
         LP_HIP(hipStreamSynchronize(st));  // the lists must outlive the copies
         if ((size_t)count > c->status_cap) {
             if (c->status_host) (void)hipHostFree(c->status_host);
@@ -664,73 +732,107 @@ static GemmArgs adat_args(lpipm_ctx* c, const Batch& bt) {
     g.C2 = (c->refine > 0 && gemm_streamk_split(c->npa / BK)) ? c->M0 : nullptr;    // only the refined solves need M itself
     return g;
 }
+static AdatUnitsArgs adat_units_args(lpipm_ctx* c, const Batch& bt) {
+    AdatUnitsArgs a{};
+    a.A = c->A; a.lda = c->npa; a.s = c->va.dinv; a.C = c->M; a.ldc = c->mp; a.K = c->npa;
+    a.C2 = (c->refine > 0 && c->cpt > 1) ? c->M0 : nullptr;                // only the refined solves need M itself
+    a.ntiles = c->ntiles; a.tile_list = c->tile_list; a.unit_list = c->unit_list; a.nunits = c->nunits; a.upc = c->upc;
+    a.window = c->window; a.diag_pad_from = (int)c->m; a.slabs = c->ws; a.tile_cnt = c->tile_cnt;
+    a.grp_cnt = nullptr; a.grp_w = POTRF_OUTER; a.batch = bt;
+    return a;
+}
+// clears the arrival counters (tiles and groups) of every LP of the batch
+static hipError_t clear_unit_counters(lpipm_ctx* c, const Batch& bt, hipStream_t st) {
+    return bt.count == 1 ? hipMemsetAsync(c->tile_cnt, 0, c->cnt_bytes, st)
+                         : hipMemset2DAsync(c->tile_cnt, (size_t)bt.stride, 0, c->cnt_bytes, (size_t)bt.count, st);
+}
 static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
-    const GemmArgs g = adat_args(c, bt);
-    hipError_t e = launch_gemm_nt(g, c->st);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    bool second_copy;
+    if (c->units) {
+        const AdatUnitsArgs a = adat_units_args(c, bt);
+        if (c->cpt > 1 && (e = clear_unit_counters(c, bt, c->st)) != hipSuccess) return e;
+        if ((e = launch_adat_units(a, c->st)) != hipSuccess) return e;
+        second_copy = a.C2 != nullptr;
+    } else {
+        const GemmArgs g = adat_args(c, bt);
+        if ((e = launch_gemm_nt(g, c->st)) != hipSuccess) return e;
+        second_copy = g.C2 != nullptr;
+    }
     e = launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M, c->mp, c->st, bt);   // + diag(D_slack)
     if (e != hipSuccess) return e;
     if (c->refine <= 0) return hipSuccess;
-    if (g.C2) return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M0, c->mp, c->st, bt);
+    if (second_copy) return launch_slack_diag(c->ns, c->nx, c->va.dinv, c->M0, c->mp, c->st, bt);
     vec_copy_lower(c->M, c->M0, c->mp, c->mp, c->st, bt);     // short contraction: one store per tile, copied afterwards
     return hipGetLastError();
 }
 
 // The normal equations AND their Cholesky factor, the factorisation running beside A.D.A^T (single LP, m >= 2048).
-// Why: the factorisation is a chain of 32 (m = 4096) dependent steps -- one 128 x 128 diagonal block on ONE CU
-// (34 us), its panel solve, the update of the next block -- that no arrangement of launches or device-side flags
-// makes shorter (a hand-off costs more than the 1.5 us kernel boundary it replaces, MI355X_MICROARCH.md price list):
-// 1.8 of its 2.3 ms keep 1-30 of 256 CUs busy.  So it is given other work to hide behind -- the 2.4 ms of A.D.A^T:
-//   * A.D.A^T is produced in COLUMN GROUPS (tile columns 4g .. 4g+3 = one outer panel of the factorisation), one
-//     stream-K launch per group on the throughput stream (CU mask: all but R CUs per XCC);
-//   * the factorisation is left-looking at the outer-panel level: before panel g is factorised, its column group gets
-//     all updates of the panels before it in ONE product (K = 512 g, the same stream-K kernel, alpha = -1, beta = 1),
-//     also on the throughput stream; inside a panel the chain is what it was (potrf_panel_chain), on the chain
-//     stream (CU mask: the R reserved CUs per XCC -- a diagonal-block kernel needs a whole CU's LDS, and on a chip
-//     full of 2-ms A.D.A^T workgroups it would wait for one);
-//   * events: group g ready (throughput -> chain), panel g done (chain -> throughput, for the update of group g+1).
+// Why: the factorisation is a chain of 32 (m = 4096) dependent steps -- one 128 x 128 diagonal block on ONE CU, its panel
+// solve, the update of the next block -- with 1-30 of 256 CUs busy for 1.4 of its 1.9 ms.  It is given other work to hide
+// behind, the 2.3 ms of A.D.A^T:
+//   * A.D.A^T is ONE launch of (tile, chunk) units in COLUMN-GROUP-MAJOR order (group g = tile columns 4g .. 4g+3 = one
+//     outer panel of the factorisation) on the throughput stream st_a (CU mask: all but R CUs per XCC).  The workgroup that
+//     completes a tile stores it write-through and bumps its group's word; group g is complete when that word reaches the
+//     group's tile count -- long before the launch ends (round 2 cut A.D.A^T into eight stream-K launches with eight tails
+//     and eight fix-ups: 2.84 + 0.25 ms against 2.35, and lost);
+//   * the factorisation is left-looking at the outer-panel level: before panel g is factorised, its column group gets the
+//     updates of all panels before it in ONE product (K = 512 g, stream-K, alpha = -1, beta = 1) on st_u -- a second stream
+//     with the throughput mask, so the update's workgroups take slots between A.D.A^T's units, which are still being
+//     dispatched -- behind a one-wave kernel that waits for the group's word (launch_wait_count);
+//   * inside a panel the chain is what it was (potrf_panel_chain), on the chain stream st_b (CU mask: the R reserved CUs
+//     per XCC: a diagonal-block kernel needs a whole CU's LDS);
+//   * events: panel g-1 done (st_b -> st_u), group g updated (st_u -> st_b).
 // The results are those of the same factorisation run alone (fixed summation orders everywhere).
-static int enqueue_factor_overlapped(lpipm_ctx* c, const Batch& bt) {
-    hipStream_t sm = c->st, sa = c->st_a, sb = c->st_b;
+static int enqueue_factor_grouped(lpipm_ctx* c, const Batch& bt) {
+    hipStream_t sm = c->st, sa = c->st_a, su = c->st_u, sb = c->st_b;
     const int ng = (int)c->grp_nt.size();
     const int wg_cus = c->num_cu - 8 * c->overlap_cus;
+    // the words the other streams poll are cleared BEFORE they are released (a wait kernel that ran ahead of the memset
+    // would see the previous iteration's full counts)
+    LP_HIP(clear_unit_counters(c, bt, sm));
     LP_HIP(hipEventRecord(c->ev_fork, sm));
     LP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
+    LP_HIP(hipStreamWaitEvent(su, c->ev_fork, 0));
     LP_HIP(hipStreamWaitEvent(sb, c->ev_fork, 0));
     LP_HIP(potrf_clear_info(c->va.potrf_info, sb, bt));
     const bool timed = c->profiling != 0;
-    hipEvent_t* ev = c->ev_adat.data() + (c->overlap_sections & 1) * 2;   // [4 g + 2 parity + {begin, end}]
+    hipEvent_t* ev = c->ev_adat.data() + (c->overlap_sections & 1) * 2;   // {begin, end} of this section's launch
+    {   // throughput stream: the whole of A.D.A^T, group by group
+        AdatUnitsArgs a = adat_units_args(c, bt);
+        a.tile_list = c->tile_list_grp; a.unit_list = c->unit_list_grp; a.nunits = c->nunits_grp;
+        a.window = 2 * wg_cus; a.grp_cnt = c->grp_cnt;
+        if (timed) LP_HIP(hipEventRecord(ev[0], sa));
+        LP_HIP(launch_adat_units(a, sa));
+        if (timed) LP_HIP(hipEventRecord(ev[1], sa));
+        LP_HIP(hipEventRecord(c->ev_adat_done, sa));
+    }
     for (int g = 0; g < ng; ++g) {
         const int J0 = g * POTRF_OUTER, J1 = J0 + POTRF_OUTER < c->mp / NB ? J0 + POTRF_OUTER : c->mp / NB;
-        // throughput stream: column group g of A.D.A^T (+ its slack diagonal), second copy to M0
-        GemmArgs a = adat_args(c, bt);
-        a.tile_list = c->tile_list_grp + c->grp_off[g]; a.ntiles = c->grp_nt[g];
-        a.nwg = gemm_streamk_nwg(a.ntiles, c->npa / BK, wg_cus);
-        if (timed) LP_HIP(hipEventRecord(ev[4 * g], sa));
-        LP_HIP(launch_gemm_nt(a, sa));
-        if (c->ns > J0 * NB) {
+        hipStream_t sg = g == 0 ? sb : su;           // group 0 needs no update: the chain stream waits for it itself
+        if (g > 0) LP_HIP(hipStreamWaitEvent(su, c->ev_chain[g - 1], 0));
+        LP_HIP(launch_wait_count(c->grp_cnt + g, (unsigned)c->grp_nt[g], bt.done, c->wait_timeout, sg));
+        if (c->ns > J0 * NB) {                       // + diag(D_slack) on the group's diagonal blocks (before the update, as alone)
             const int r0 = J0 * NB, cnt = (c->ns < J1 * NB ? c->ns : J1 * NB) - r0;
-            LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
-            if (a.C2) LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M0 + (size_t)r0 * (c->mp + 1), c->mp, sa, bt));
+            LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M + (size_t)r0 * (c->mp + 1), c->mp, sg, bt));
+            if (c->refine > 0) LP_HIP(launch_slack_diag(cnt, c->nx, c->va.dinv + r0, c->M0 + (size_t)r0 * (c->mp + 1), c->mp, sg, bt));
         }
-        if (timed) LP_HIP(hipEventRecord(ev[4 * g + 1], sa));
         if (g > 0) {   // ... minus what the panels before it contribute: C -= L[rows, 0:K) . L[cols, 0:K)^T
-            LP_HIP(hipStreamWaitEvent(sa, c->ev_chain[g - 1], 0));
             GemmArgs u{};
             u.P = c->M; u.ldp = c->mp; u.Q = c->M; u.ldq = c->mp; u.s = nullptr;
             u.C = c->M; u.ldc = c->mp; u.K = J0 * NB; u.alpha = -1.0; u.beta = 1.0;
             u.ntiles = c->grp_nt[g]; u.tiles_lower = 1; u.tile_list = c->tile_list_grp + c->grp_off[g];
-            u.diag_pad_from = -1; u.ws = c->ws; u.batch = bt; u.sk_claim = c->sk_claim; u.streamk = 1;
+            u.diag_pad_from = -1; u.ws = c->ws_upd; u.batch = bt; u.sk_claim = c->sk_claim_upd; u.streamk = 1;
             u.nwg = gemm_streamk_nwg(u.ntiles, u.K / BK, wg_cus);
-            LP_HIP(launch_gemm_nt(u, sa));
+            LP_HIP(launch_gemm_nt(u, su));
+            LP_HIP(hipEventRecord(c->ev_ready[g], su));
+            LP_HIP(hipStreamWaitEvent(sb, c->ev_ready[g], 0));
         }
-        LP_HIP(hipEventRecord(c->ev_ready[g], sa));
-        // chain stream: panel g
-        LP_HIP(hipStreamWaitEvent(sb, c->ev_ready[g], 0));
         LP_HIP(potrf_panel_chain(c->M, c->mp, c->mp, c->plan, c->va.potrf_info, sb, bt, J0, J1));
         LP_HIP(hipEventRecord(c->ev_chain[g], sb));
     }
-    LP_HIP(hipStreamWaitEvent(sm, c->ev_chain[ng - 1], 0));    // everything on the throughput stream precedes it
+    LP_HIP(hipStreamWaitEvent(sm, c->ev_chain[ng - 1], 0));
+    LP_HIP(hipStreamWaitEvent(sm, c->ev_adat_done, 0));        // (complete by then: every group word was waited for)
     LP_HIP(potrf_superblock_inverses(c->plan, sm, bt));
     return LPIPM_OK;
 }
@@ -779,6 +881,8 @@ static int copy_status(lpipm_ctx* c) {
     if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, c->va.status, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
     else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), c->va.status, c->bstride, sizeof(StatusRec), (size_t)c->B,
                                  hipMemcpyDeviceToHost, c->st));
+    if (c->factor_in_head)     // a wait kernel of the side-by-side section that gave up (its producer never ran) says so here
+        LP_HIP(hipMemcpyAsync(c->timeout_host, c->wait_timeout, sizeof(unsigned int), hipMemcpyDeviceToHost, c->st));
     return LPIPM_OK;
 }
 
@@ -797,7 +901,7 @@ static int enqueue_head(lpipm_ctx* c) {
     vec_pred_setup(vh, st);
     if (c->factor_in_head) {   // A.D.A^T and the Cholesky factorisation side by side (newton_equations.rs:55-57, :129-131)
         prof_mark(c, T_VEC);
-        LP_TRY(enqueue_factor_overlapped(c, c->bt_head));
+        LP_TRY(enqueue_factor_grouped(c, c->bt_head));
         prof_mark(c, T_POTRF);
         c->overlap_sections++;
         return LPIPM_OK;
@@ -971,6 +1075,11 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
             prof_collect_overlap(c, c->overlap_sections - (head_out ? 2 : 1));
         }
         ++adat_launches;
+        if (c->factor_in_head && *c->timeout_host != 0) {
+            g_err_detail = "a group of A.D.A^T did not complete within the wait kernel's bound (side-by-side factorisation)";
+            LP_HIP(hipStreamSynchronize(st));
+            return LPIPM_ERR_HIP;
+        }
         const StatusRec s = *c->status_host;
         // EquationSolverType::build failure (newton_equations.rs:58-63) and the NaN check on p, q
         // (:190-194) both surface as NumericalProblem from get_delta (mod.rs:215)
@@ -1157,11 +1266,8 @@ static size_t lockstep_bytes_per_lp(const lpipm_ctx* c, uint64_t m, uint64_t n) 
     t.num_cu = c->num_cu; t.refine = c->refine; t.B = 32;
     t.mp = (int)round_up(m, NB); t.np = (int)round_up(n, BK); t.npa = t.np;
     t.nsplit = t.mp / GEMVT_ROWS;
-    const int nt = t.mp / TILE;
-    t.ntiles = nt * (nt + 1) / 2;
-    t.adat_nwg = 2 * t.num_cu / t.B < 1 ? 1 : 2 * t.num_cu / t.B;
-    if (t.adat_nwg > t.ntiles) t.adat_nwg = t.ntiles;
-    t.ws_slabs = gemm_streamk_slabs(t.ntiles, t.npa / BK, t.adat_nwg);
+    t.units_env = c->units_env;
+    plan_adat(&t, t.B);
     Arena measure;
     if (layout_problem(&t, measure, false) != LPIPM_OK) return (size_t)-1;
     return (size_t)round_up(measure.off, 4096);
