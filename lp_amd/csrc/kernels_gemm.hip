@@ -482,10 +482,11 @@ struct UnitsK {
     double* C; long long ldc;
     double* C2;
     int KT, kc, cpt;
+    int nbig, ks;             // chunk q covers k-tiles [q*kc, (q+1)*kc) for q < nbig, then pieces of ks k-tiles (adat_units_chunking)
     int ntiles;
     const int2* tile_list;
     const int2* unit_list;
-    int nunits, upc, window;
+    int nunits, upc;
     int diag_pad_from;
     double* slabs;
     unsigned int* tile_cnt;
@@ -493,17 +494,6 @@ struct UnitsK {
     int grp_w;
     BatchK bk;
 };
-// Workgroups are dispatched in index order and dealt to the 8 XCDs round-robin: inside a window of `w` consecutive
-// indices (the workgroups resident together) XCD x gets the contiguous logical range [x*w/8, (x+1)*w/8) -- consecutive
-// units of the list (same k-range, neighbouring tiles) share one L2.
-__device__ __forceinline__ int window_remap(int b, int w, int n) {
-    const int base = (b / w) * w;
-    const int len = n - base < w ? n - base : w;       // the last window may be short
-    const int r = b - base;
-    const int q = len >> 3, rem = len & 7, x = r & 7;
-    return base + (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (r >> 3);
-}
-
 template <bool GRP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt_units_kernel(const UnitsK p0) {
     if (batch_done(p0.bk)) return;
@@ -518,8 +508,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int fr = lane & 15, fq = lane >> 4;
     const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
     const int b = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
-    const int2 un = p.unit_list[p.bk.xcd_major ? b : window_remap(b, p.window, p.nunits)];   // xcd-major: one LP per XCD anyway
+    const int2 un = p.unit_list[b];          // the list is already dealt to the XCDs (solver.hip, deal_units)
     const int tile = un.x, q0 = un.y;
+    if (tile < 0) return;                    // padding of an XCD's shorter list
     const int q1 = q0 + p.upc < p.cpt ? q0 + p.upc : p.cpt;
     const int2 tc = p.tile_list[tile];
     const int ti = tc.x, tj = tc.y;
@@ -539,7 +530,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int kb = q0 * p.kc, ke = q1 * p.kc < KT ? q1 * p.kc : KT;
+    // chunk boundaries: nbig chunks of kc k-tiles, the rest of the contraction in pieces of ks
+    auto chunk_begin = [&](int q) { const int b0 = q <= p.nbig ? q * p.kc : p.nbig * p.kc + (q - p.nbig) * p.ks; return b0 < KT ? b0 : KT; };
+    const int kb = chunk_begin(q0), ke = chunk_begin(q1);
     if (p.cpt == 1) {
         // a contraction of one chunk: the unit is the whole tile, stored directly
         tile_pass_w8<true>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq, 0,
@@ -953,8 +946,9 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     if (a.C2 && (cpt == 1 || a.beta != 0.0)) return hipErrorInvalidValue;   // the second copy comes from a tile's last flush / the fix-up
     if (nrem > 0) {
         if (cpt > 1 && !a.ws) return hipErrorInvalidValue;
-        hipError_t em = B == 1 ? hipMemsetAsync(a.sk_claim, 0, sizeof(unsigned int), st)
-                               : hipMemset2DAsync(a.sk_claim, (size_t)a.batch.stride, 0, sizeof(unsigned int), (size_t)B, st);
+        unsigned int* claim = (unsigned int*)((char*)a.sk_claim + (size_t)a.batch.first * (size_t)a.batch.stride);
+        hipError_t em = B == 1 ? hipMemsetAsync(claim, 0, sizeof(unsigned int), st)
+                               : hipMemset2DAsync(claim, (size_t)a.batch.stride, 0, sizeof(unsigned int), (size_t)B, st);
         if (em != hipSuccess) return em;
     }
     // a batch of a multiple of 8 LPs: one LP per XCD at a time (see BatchK)
@@ -973,23 +967,42 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t st) {
     return e;
 }
 
-int adat_units_cpt(int K) {
+// The canonical chunking of the A.D.A^T contraction in the units kernel.  Up to KT = 256 k-tiles (n <= 4096): uniform chunks
+// of gemm_streamk_chunk(KT) -- the chunking of the round-2 kernel, so that an LP gets the same bits from either (the sizes
+// that run alone and as lockstep batches).  Above: chunks of 64 k-tiles (1024 columns), except that the LAST 64 are cut
+// into pieces of 16: units are dispatched in chunk order, so the launch ends on quarter-size units -- with 4224 equal units
+// on 512 slots the last quarter-full round of 0.25 ms units cost 0.19 ms of a 2.3 ms launch.
+int adat_units_chunking(int K, int* kc_out, int* nbig_out, int* ks_out) {
     const int KT = K / BK, kc = gemm_streamk_chunk(KT);
-    return KT <= kc ? 1 : (KT + kc - 1) / kc;
+    int nbig, ks, cpt;
+    if (KT <= kc) { nbig = 1; ks = kc; cpt = 1; }
+    else if (KT <= 256 || kc < 32) { ks = kc; cpt = (KT + kc - 1) / kc; nbig = cpt; }
+    else {
+        nbig = KT / kc - 1;                 // full chunks but the last one
+        ks = kc / 4;
+        cpt = nbig + (KT - nbig * kc + ks - 1) / ks;
+    }
+    if (kc_out) *kc_out = kc;
+    if (nbig_out) *nbig_out = nbig;
+    if (ks_out) *ks_out = ks;
+    return cpt;
 }
+int adat_units_cpt(int K) { return adat_units_chunking(K, nullptr, nullptr, nullptr); }
 
 hipError_t launch_adat_units(const AdatUnitsArgs& a, hipStream_t st) {
     if (a.ntiles <= 0 || a.nunits <= 0 || a.K <= 0) return hipSuccess;
     if (a.lda >= (1 << 22) || a.ldc >= (1 << 22)) return hipErrorInvalidValue;   // 128-row panels are 32-bit buffers
-    if (!a.A || !a.s || !a.C || !a.tile_list || !a.unit_list || a.upc < 1 || a.window < 8 || a.window % 8) return hipErrorInvalidValue;
+    if (!a.A || !a.s || !a.C || !a.tile_list || !a.unit_list || a.upc < 1) return hipErrorInvalidValue;
     UnitsK k{};
     k.A = a.A; k.lda = a.lda; k.s = a.s; k.C = a.C; k.ldc = a.ldc; k.C2 = a.C2;
-    k.KT = a.K / BK; k.kc = gemm_streamk_chunk(k.KT); k.cpt = adat_units_cpt(a.K);
+    k.KT = a.K / BK;
+    k.cpt = adat_units_chunking(a.K, &k.kc, &k.nbig, &k.ks);
     if (k.cpt == 1) k.kc = 0;
+    if (a.upc > 1 && k.nbig != k.cpt) return hipErrorInvalidValue;     // several chunks per unit: uniform chunking only
     if (k.cpt > 1 && (!a.slabs || !a.tile_cnt)) return hipErrorInvalidValue;
     if (k.cpt > 256) return hipErrorInvalidValue;          // a tile's slabs are one 32-bit buffer
     k.ntiles = a.ntiles; k.tile_list = a.tile_list; k.unit_list = a.unit_list; k.nunits = a.nunits; k.upc = a.upc;
-    k.window = a.window; k.diag_pad_from = a.diag_pad_from; k.slabs = a.slabs; k.tile_cnt = a.tile_cnt;
+    k.diag_pad_from = a.diag_pad_from; k.slabs = a.slabs; k.tile_cnt = a.tile_cnt;
     k.grp_cnt = a.grp_cnt; k.grp_w = a.grp_w > 0 ? a.grp_w : 1; k.bk = batch_k(a.batch);
     const int B = a.batch.count;
     const bool xm = B >= 8 && B % 8 == 0;                  // one LP per XCD at a time (see BatchK)

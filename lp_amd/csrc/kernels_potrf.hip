@@ -623,6 +623,7 @@ constexpr int OUTER = POTRF_OUTER;
 
 hipError_t potrf_clear_info(int32_t* info, hipStream_t st, const Batch& bt) {
     // (a finished LP of a batch has its info word cleared too: its status record already holds the value)
+    info = (int32_t*)((char*)info + (size_t)bt.first * (size_t)bt.stride);
     return bt.count == 1 ? hipMemsetAsync(info, 0, sizeof(int32_t), st)
                          : hipMemset2DAsync(info, (size_t)bt.stride, 0, sizeof(int32_t), (size_t)bt.count, st);
 }

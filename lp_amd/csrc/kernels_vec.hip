@@ -56,9 +56,9 @@ __device__ __forceinline__ double fold_min(const double* red, int slot, int nblk
 
 // LP blockIdx.z of a lockstep batch.  `check_done`: kernels of the iteration skip an LP that has finished.
 __device__ __forceinline__ bool vbatch(VecArgs& a, bool check_done) {
-    const BatchK bk{a.bstride, check_done ? a.done_chk : nullptr, 0};
+    const BatchK bk{a.bstride, check_done ? a.done_chk : nullptr, 0, a.bfirst};
     if (batch_done(bk)) return false;
-    if (blockIdx.z == 0) return true;
+    if (blockIdx.z == 0 && a.bfirst == 0) return true;
     a.b = batch_ptr(a.b, bk); a.c = batch_ptr(a.c, bk);
     a.x = batch_ptr(a.x, bk); a.y = batch_ptr(a.y, bk); a.z = batch_ptr(a.z, bk);
     a.dinv = batch_ptr(a.dinv, bk); a.xs = batch_ptr(a.xs, bk); a.r1 = batch_ptr(a.r1, bk); a.rD = batch_ptr(a.rD, bk);
@@ -409,7 +409,7 @@ __global__ void k_step_scalars(VecArgs a, int ip) {
 // x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
 __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
     if (!vbatch(a, false)) return;
-    xout = batch_ptr(xout, BatchK{a.bstride, nullptr, 0});
+    xout = batch_ptr(xout, BatchK{a.bstride, nullptr, 0, a.bfirst});
     const int stride = gridDim.x * 256;
     const double tau = a.S[S_TAU];
     double acc[1] = {0};

@@ -38,15 +38,17 @@ struct Batch {
     int count = 1;
     long long stride = 0;
     const int* done = nullptr;
+    int first = 0;        // a launch may cover only the LPs [first, first + count) of the resident batch (pointers stay LP 0's)
 };
+inline Batch batch_slice(const Batch& b, int first, int count) { return Batch{count, b.stride, b.done, b.first + first}; }
 // The part a kernel needs.  xcd_major (A.D.A^T only, count a multiple of 8): grid = (8, workgroups per LP,
 // count / 8) and LP = 8*blockIdx.z + blockIdx.x -- workgroups are dealt to the 8 XCDs round-robin along x,
 // so all workgroups of one LP share one XCD's L2 and re-use each other's panels of A.
-struct BatchK { long long stride; const int* done; int xcd_major; };
-inline BatchK batch_k(const Batch& b) { return BatchK{b.stride, b.done, 0}; }
+struct BatchK { long long stride; const int* done; int xcd_major; int first; };
+inline BatchK batch_k(const Batch& b) { return BatchK{b.stride, b.done, 0, b.first}; }
 #ifdef __HIPCC__
 __device__ __forceinline__ long long batch_lp(const BatchK& b) {
-    return b.xcd_major ? (long long)blockIdx.z * 8 + blockIdx.x : (long long)blockIdx.z;
+    return (long long)b.first + (b.xcd_major ? (long long)blockIdx.z * 8 + blockIdx.x : (long long)blockIdx.z);
 }
 __device__ __forceinline__ bool batch_done(const BatchK& b) {
     return b.done && *(const int*)((const char*)b.done + batch_lp(b) * b.stride) != 0;
@@ -129,9 +131,8 @@ struct AdatUnitsArgs {
     int K;                            // columns (multiple of BK)
     int ntiles;
     const int2* tile_list;            // (ti, tj) per tile, device
-    const int2* unit_list;            // (tile index, first chunk) per unit in dispatch order, device
+    const int2* unit_list;            // (tile index, first chunk) per unit in dispatch order, device; tile < 0: padding (no-op)
     int nunits, upc;
-    int window;                       // workgroups resident together (slots), multiple of 8: XCD-aware renumbering inside windows
     int diag_pad_from;
     double* slabs;                    // ntiles * cpt slabs of TILE*TILE doubles
     unsigned int* tile_cnt;           // ntiles arrival counters, ZEROED before the launch (by the caller, in stream order)
@@ -140,6 +141,7 @@ struct AdatUnitsArgs {
     Batch batch;
 };
 int adat_units_cpt(int K);            // chunks per tile for a contraction of K columns
+int adat_units_chunking(int K, int* kc, int* nbig, int* ks);   // ... and their boundaries (kernels_gemm.hip)
 hipError_t launch_adat_units(const AdatUnitsArgs& a, hipStream_t st);
 // One wave that returns when *cnt >= target (or when *done != 0, or after a bounded number of polls, which sets *timeout):
 // the device-side wait of a stream for a group word of a running launch on another stream.

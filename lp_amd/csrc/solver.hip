@@ -61,7 +61,7 @@ struct lpipm_ctx {
     int units_env = 1;                   // LPIPM_ADAT_UNITS=0: the round-2 kernel (data-parallel tiles + stream-K + fix-up launch)
     bool units = false;                  // this problem runs the units kernel (geometry: the slabs fit the budget)
     int cpt = 1, upc = 1;                // chunks per tile, chunks per unit
-    int nunits = 0, nunits_grp = 0, window = 512;
+    int nunits = 0, nunits_grp = 0;
     int2* unit_list = nullptr;           // (tile, first chunk) in dispatch order: chunk-major over the XCD-aware tile order
     int2* unit_list_grp = nullptr;       // column-group-major (tile indices into tile_list_grp): groups complete one after the other
     unsigned int* tile_cnt = nullptr;    // arena: arrival counters of the tiles, then the group words (one memset clears both)
@@ -82,6 +82,11 @@ struct lpipm_ctx {
     std::vector<int> grp_off, grp_nt;    // tile sub-list of every column group (outer panel of the factorisation)
     hipEvent_t ev_fork = nullptr;
     PotrfLookahead la;                   // trailing updates of one factorisation beside the next panel's chain (launch_potrf)
+    // a lockstep batch as two half-batches driven by two host threads on two streams (solve_lockstep): views of this
+    // context that share its arena (every pointer is LP 0's; a view's launches cover the LPs [bt.first, bt.first + B))
+    bool is_view = false;
+    int halves_env = 1;                  // LPIPM_HALVES=0: one stream for the whole batch
+    std::vector<lpipm_ctx*> halves;
     std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
     int refine = 0;              // set from the environment by lpipm_create.  0 (default): plain solves; LPIPM_REFINE=2: every
                                  //   solve of every iteration refined; =1: only from mu / mu_0 <= refine_below() on.
@@ -132,6 +137,8 @@ struct lpipm_ctx {
     double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
     size_t mpack_count = 0;
 };
+
+static void destroy_views(lpipm_ctx* c);      // half-batch views of a lockstep batch (solve_lockstep)
 
 // The factorisation beside A.D.A^T (enqueue_factor_grouped) unless LPIPM_OVERLAP says otherwise: see lpipm_create.
 constexpr bool OVERLAP_DEFAULT = false;
@@ -295,7 +302,12 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     // LPIPM_REFINE (see lpipm_ctx::refine) is read ONCE, here: the arena layout depends on it (M0, R0, Rho and the symv slabs
     // exist only for a refining context: 134 MB at C3, 2 GB at m = 16384, per member of a lockstep batch)
     { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
-    { const char* e = getenv("LPIPM_ADAT_UNITS"); c->units_env = (e && e[0] == '0') ? 0 : 1; }
+    // LPIPM_ADAT_UNITS: 0 = the round-2 kernel everywhere, 2 = the units kernel for single LPs too (measurement / test knob);
+    // default 1 = units kernel for lockstep batches and for the side-by-side factorisation, round-2 kernel for a single LP
+    // (measured per launch, units vs round-2: 512x1024 0.042 / 0.045 ms, 1024x2048 0.102 / 0.097, 2048x4096 0.469 / 0.458,
+    // 4096x8192 2.47 / 2.39 standalone and 2.32 / 2.25 inside a solve; C4 lockstep shard 1732 vs 1674 LP/s)
+    { const char* e = getenv("LPIPM_ADAT_UNITS"); c->units_env = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }
+    { const char* e = getenv("LPIPM_HALVES"); c->halves_env = (e && e[0] == '0') ? 0 : 1; }
     if (hipHostMalloc((void**)&c->timeout_host, sizeof(unsigned int)) != hipSuccess) {
         g_err_detail = "failed to allocate the pinned time-out word";
         lpipm_destroy(c);
@@ -369,6 +381,7 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (!c) return;
     for (lpipm_ctx* w : c->workers) lpipm_destroy(w);
     c->workers.clear();
+    destroy_views(c);
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     drop_graphs(c);
@@ -451,6 +464,27 @@ static int merge_edge_for(int) {
     return 32;
 }
 
+// The unit list of a single LP's A.D.A^T launch, dealt to the XCDs.  Workgroup b of a launch runs on XCD b % 8 (round-robin
+// dispatch), so entry b of the list belongs to XCD b % 8: every XCD gets its OWN tiles (full rounds of 512 tiles: 64
+// consecutive tiles of the order = one 8 x 8 super-block sharing 16 row panels of A; the rest in contiguous eighths) and
+// walks them chunk by chunk -- the workgroups resident on one XCD (one L2) are one k-range of neighbouring tiles for the
+// whole launch, like the data-parallel phase of the round-2 kernel.  Shorter lists are padded with no-op entries.
+// tiles: indices into the launch's tile list, in its order; chunks q0, q0 + upc, ... < cpt per tile.
+static void deal_units(const std::vector<int>& tiles, int cpt, int upc, std::vector<int2>& out) {
+    std::vector<int> own[8];
+    const int nt = (int)tiles.size(), full = nt / 512 * 512, rest = nt - full;
+    for (int i = 0; i < full; ++i) own[(i % 512) / 64].push_back(tiles[(size_t)i]);
+    for (int x = 0; x < 8; ++x)
+        for (int i = full + (int)((long long)rest * x / 8); i < full + (int)((long long)rest * (x + 1) / 8); ++i) own[x].push_back(tiles[(size_t)i]);
+    size_t longest = 0;
+    for (int x = 0; x < 8; ++x) longest = own[x].size() > longest ? own[x].size() : longest;
+    const int nq = (cpt + upc - 1) / upc;
+    for (int q = 0; q < nq; ++q)                           // chunk-major inside an XCD's list
+        for (size_t i = 0; i < longest; ++i)
+            for (int x = 0; x < 8; ++x)
+                out.push_back(i < own[x].size() ? make_int2(own[x][i], q * upc) : make_int2(-1, 0));
+}
+
 // How the A.D.A^T launch of this geometry is cut up (a function of mp, npa, the batch count and the CU count alone).
 static void plan_adat(lpipm_ctx* c, int count) {
     const int nt = c->mp / TILE;
@@ -472,10 +506,14 @@ static void plan_adat(lpipm_ctx* c, int count) {
     // A.D.A^T as (tile, chunk) units: every chunk sum goes through its own slab (ntiles x cpt slabs of 128 KiB per LP:
     // 0.55 GB at C3, 38 MB per member at C4) -- up to 4 GiB per LP, beyond that (m = 16384: 34 GB) the round-2 kernel
     c->cpt = adat_units_cpt(c->npa);
-    c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30);
+    c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30) &&
+               (count > 1 || c->units_env == 2 || c->st_a != nullptr);
     // a single LP: one chunk per unit (parallelism, and column groups that complete while the launch runs); a lockstep
-    // batch fills the chip with whole tiles: one unit = all chunks of a tile, its own workgroup adds its slabs at the end
-    c->upc = count == 1 ? 1 : c->cpt;
+    // batch: two chunks per unit -- whole tiles (one unit = all chunks, its own workgroup adds its slabs) leave the last of
+    // 2.25 rounds of tiles a quarter full (C4 shard: 1633 LP/s, against 1706 with one chunk per unit, 1533 / 1521 / 1521 at
+    // 2 / 1 / 4 chunks on a slower box)
+    c->upc = count == 1 ? 1 : (c->cpt < 2 ? c->cpt : 2);
+    { int kc, nbig, ks; if (adat_units_chunking(c->npa, &kc, &nbig, &ks) != nbig) c->upc = 1; }   // non-uniform chunks: one per unit
     if (const char* e = getenv("LPIPM_ADAT_UPC")) { const int v = atoi(e); if (v >= 1) c->upc = v < c->cpt ? v : c->cpt; }   // measurement knob
     if (c->units && c->ws_slabs < (size_t)c->ntiles * c->cpt) c->ws_slabs = (size_t)c->ntiles * c->cpt;
 }
@@ -557,6 +595,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     }
     LP_HIP(hipSetDevice(c->device));
     drop_graphs(c);   // kernel arguments depend on m, n, n_slack and the buffers
+    destroy_views(c); // half-batch views copy the geometry and the buffers
     const uint64_t nx = n - n_slack;
     const int mp = (int)round_up(m, NB), np = (int)round_up(n, BK), npa = (int)round_up(nx, BK);
     hipStream_t st = c->st;
@@ -576,11 +615,16 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         plan_adat(c, count);
         std::vector<int2> units, units_grp;
         if (c->units) {
-            for (int q = 0; q < c->cpt; q += c->upc)               // chunk-major: the units resident together are ONE k-range of
-                for (int t = 0; t < c->ntiles; ++t) units.push_back(make_int2(t, q));   // neighbouring tiles (panels shared in L2)
+            if (count == 1) {
+                std::vector<int> all((size_t)c->ntiles);
+                for (int t = 0; t < c->ntiles; ++t) all[(size_t)t] = t;
+                deal_units(all, c->cpt, c->upc, units);
+            } else {                                               // a batch: an LP's units all run on one XCD (xcd-major grid)
+                for (int q = 0; q < c->cpt; q += c->upc)
+                    for (int t = 0; t < c->ntiles; ++t) units.push_back(make_int2(t, q));
+            }
         }
         c->nunits = (int)units.size();
-        c->window = 2 * c->num_cu;
         // Factorisation beside A.D.A^T: single LP, big enough that A.D.A^T can hide the factorisation's chain
         c->overlap = count == 1 && c->st_a != nullptr && mp >= 2048 && c->units && c->cpt > 1 && nt <= 64 * POTRF_OUTER;
         std::vector<int2> grouped;
@@ -589,8 +633,9 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
             grouped = adat_tile_order_grouped(nt, c->grp_off, c->grp_nt);
             const int wg_cus = c->num_cu - 8 * c->overlap_cus;
             for (size_t g = 0; g < c->grp_nt.size(); ++g) {
-                for (int q = 0; q < c->cpt; ++q)                   // group-major, chunk-major inside a group
-                    for (int t = 0; t < c->grp_nt[g]; ++t) units_grp.push_back(make_int2(c->grp_off[g] + t, q));
+                std::vector<int> grp((size_t)c->grp_nt[g]);        // group-major; inside a group dealt to the XCDs, chunk-major
+                for (int t = 0; t < c->grp_nt[g]; ++t) grp[(size_t)t] = c->grp_off[g] + t;
+                deal_units(grp, c->cpt, 1, units_grp);
                 const int ku = (int)g * POTRF_OUTER * NB / BK;      // contraction of the left-looking update of group g
                 const size_t s2 = ku ? gemm_streamk_slabs(c->grp_nt[g], ku, gemm_streamk_nwg(c->grp_nt[g], ku, wg_cus)) : 0;
                 if (s2 > c->ws_upd_slabs) c->ws_upd_slabs = s2;
@@ -637,7 +682,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         }
         VecArgs& v = c->va;
         v.np = np; v.mp = mp; v.nblk = c->nblk; v.nsplit = c->nsplit;
-        v.bcount = count; v.bstride = (long long)c->bstride; v.refine_below = refine_below();
+        v.bcount = count; v.bstride = (long long)c->bstride; v.bfirst = 0; v.refine_below = refine_below();
     } else {
         // same padded geometry: clear the whole state, so no stale (possibly non-finite) value of a
         // previous problem can sit in a padding lane
@@ -737,14 +782,15 @@ static AdatUnitsArgs adat_units_args(lpipm_ctx* c, const Batch& bt) {
     a.A = c->A; a.lda = c->npa; a.s = c->va.dinv; a.C = c->M; a.ldc = c->mp; a.K = c->npa;
     a.C2 = (c->refine > 0 && c->cpt > 1) ? c->M0 : nullptr;                // only the refined solves need M itself
     a.ntiles = c->ntiles; a.tile_list = c->tile_list; a.unit_list = c->unit_list; a.nunits = c->nunits; a.upc = c->upc;
-    a.window = c->window; a.diag_pad_from = (int)c->m; a.slabs = c->ws; a.tile_cnt = c->tile_cnt;
+    a.diag_pad_from = (int)c->m; a.slabs = c->ws; a.tile_cnt = c->tile_cnt;
     a.grp_cnt = nullptr; a.grp_w = POTRF_OUTER; a.batch = bt;
     return a;
 }
 // clears the arrival counters (tiles and groups) of every LP of the batch
 static hipError_t clear_unit_counters(lpipm_ctx* c, const Batch& bt, hipStream_t st) {
-    return bt.count == 1 ? hipMemsetAsync(c->tile_cnt, 0, c->cnt_bytes, st)
-                         : hipMemset2DAsync(c->tile_cnt, (size_t)bt.stride, 0, c->cnt_bytes, (size_t)bt.count, st);
+    char* p = (char*)c->tile_cnt + (size_t)bt.first * (size_t)bt.stride;
+    return bt.count == 1 ? hipMemsetAsync(p, 0, c->cnt_bytes, st)
+                         : hipMemset2DAsync(p, (size_t)bt.stride, 0, c->cnt_bytes, (size_t)bt.count, st);
 }
 static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     hipError_t e;
@@ -801,7 +847,7 @@ static int enqueue_factor_grouped(lpipm_ctx* c, const Batch& bt) {
     {   // throughput stream: the whole of A.D.A^T, group by group
         AdatUnitsArgs a = adat_units_args(c, bt);
         a.tile_list = c->tile_list_grp; a.unit_list = c->unit_list_grp; a.nunits = c->nunits_grp;
-        a.window = 2 * wg_cus; a.grp_cnt = c->grp_cnt;
+        a.grp_cnt = c->grp_cnt;
         if (timed) LP_HIP(hipEventRecord(ev[0], sa));
         LP_HIP(launch_adat_units(a, sa));
         if (timed) LP_HIP(hipEventRecord(ev[1], sa));
@@ -844,7 +890,7 @@ static int chol_solve_refined(lpipm_ctx* c, int nrhs, double* R, const Batch& bt
     hipStream_t st = c->st;
     if (!c->refine_now) { LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt)); return LPIPM_OK; }
     // the refinement's launches skip an LP whose own word says so (a finished one, or one that does not need it yet)
-    const Batch br = c->refine == 2 ? bt : Batch{bt.count, bt.stride, c->va.skip_refine};
+    const Batch br = c->refine == 2 ? bt : Batch{bt.count, bt.stride, c->va.skip_refine, bt.first};
     vec_rows_copy(c->mp, nrhs, c->R0, R, st, br);
     LP_HIP(launch_chol_solve(c->M, c->mp, c->plan, nrhs, R, c->Y, st, bt));
     LP_HIP(launch_symv_residual(c->M0, c->mp, c->mp, nrhs, R, c->mp, c->R0, c->mp, c->Rho, c->mp, c->symv_ws, st, br));
@@ -878,9 +924,9 @@ static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol)
 
 // status records of all LPs of the context -> pinned host array (96 bytes each)
 static int copy_status(lpipm_ctx* c) {
-    if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, c->va.status, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
-    else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), c->va.status, c->bstride, sizeof(StatusRec), (size_t)c->B,
-                                 hipMemcpyDeviceToHost, c->st));
+    if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, (const char*)c->va.status + (size_t)c->bt.first * c->bstride, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
+    else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), (const char*)c->va.status + (size_t)c->bt.first * c->bstride, c->bstride,
+                                 sizeof(StatusRec), (size_t)c->B, hipMemcpyDeviceToHost, c->st));
     if (c->factor_in_head)     // a wait kernel of the side-by-side section that gave up (its producer never ran) says so here
         LP_HIP(hipMemcpyAsync(c->timeout_host, c->wait_timeout, sizeof(unsigned int), hipMemcpyDeviceToHost, c->st));
     return LPIPM_OK;
@@ -1141,6 +1187,54 @@ extern "C" int lpipm_solve_device(lpipm_ctx* c, const lpipm_opts* o, void* x_dev
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- half-batch views -------------------------------------------------------------------------------------------------
+static void destroy_views(lpipm_ctx* c) {
+    for (lpipm_ctx* v : c->halves) {
+        (void)hipSetDevice(v->device);
+        if (v->st) { (void)hipStreamSynchronize(v->st); (void)hipStreamDestroy(v->st); }
+        for (hipEvent_t e : v->events) (void)hipEventDestroy(e);
+        if (v->ev_begin) (void)hipEventDestroy(v->ev_begin);
+        if (v->ev_end) (void)hipEventDestroy(v->ev_end);
+        if (v->ev_status) (void)hipEventDestroy(v->ev_status);
+        if (v->status_host) (void)hipHostFree(v->status_host);
+        if (v->timeout_host) (void)hipHostFree(v->timeout_host);
+        v->plan = FactorPlan{};            // shares the parent's descriptors: never destroyed here
+        delete v;
+    }
+    c->halves.clear();
+}
+// A view of the LPs [first, first + count) of c's resident batch: the same device state (every pointer stays LP 0's), its own
+// stream, events and pinned status records.
+static lpipm_ctx* make_view(const lpipm_ctx* c, int first, int count) {
+    lpipm_ctx* v = new lpipm_ctx(*c);
+    v->is_view = true;
+    v->halves.clear(); v->workers.clear(); v->graphs.clear(); v->kallocs.clear();
+    v->events.clear(); v->mark_tags.clear(); v->nmarks = 0;
+    v->ev_ready.clear(); v->ev_chain.clear(); v->ev_adat.clear(); v->la = PotrfLookahead{};
+    v->st = nullptr; v->st_a = v->st_b = v->st_u = nullptr; v->ev_fork = v->ev_adat_done = nullptr; v->overlap = false;
+    v->ev_begin = v->ev_end = v->ev_status = nullptr; v->status_host = nullptr; v->timeout_host = nullptr;
+    v->mpack = nullptr; v->kM = v->kM0 = v->kR = v->kY = nullptr; v->kmp = 0; v->kplan = FactorPlan{};
+    v->profiling = 0;
+    v->B = count;
+    v->bt = Batch{count, (long long)c->bstride, c->va.done, first};
+    v->bt_head = v->bt;
+    v->va.bcount = count; v->va.bfirst = first; v->va.done_chk = c->va.done;
+    v->status_cap = (size_t)count;
+    if (hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&v->status_host, (size_t)count * sizeof(StatusRec)) != hipSuccess ||
+        hipHostMalloc((void**)&v->timeout_host, sizeof(unsigned int)) != hipSuccess ||
+        hipEventCreate(&v->ev_begin) != hipSuccess || hipEventCreate(&v->ev_end) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_status, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        lpipm_ctx tmp_owner;               // release what was made
+        tmp_owner.halves.push_back(v);
+        destroy_views(&tmp_owner);
+        return nullptr;
+    }
+    *v->timeout_host = 0;
+    return v;
+}
+
 // Lockstep batch: B LPs of one shape resident at once (upload_impl with count = B), every launch of the
 // iteration covering all of them (gridDim.z = B).  The ~100 dependent launches per iteration -- the
 // latency floor of a small LP -- are then paid once per B LPs.  LPs finish at different iterations:
@@ -1154,8 +1248,48 @@ struct XOut {
     size_t stride_bytes = 0;
     bool valid() const { return host || dev; }
 };
+static int solve_lockstep_one(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, const uint64_t* rows, double* fun_out,
+                              uint64_t* its_out, int32_t* status_out);
+// A batch of at least 16 members is solved as TWO half-batches, each by its own host thread on its own stream (views of the
+// context): the halves drift out of phase, and one half's A.D.A^T (MFMA-bound, fills the chip) runs beside the other half's
+// factorisation chain, solves and passes over A (latency- and HBM-bound).  Every member goes through exactly the kernels
+// and arguments of the one-stream path: the results are bit-identical (tests/test_gpu_c4_members.py).  Measured on the C4
+// shard (32 x 1024x2048): +3 .. +6.5 % (profiles/r03_rejected_experiments.txt has the variants).  Not while profiling (the
+// phase marks are per stream) and not for the views themselves.
 static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, const uint64_t* rows, double* fun_out,
                           uint64_t* its_out, int32_t* status_out) {
+    if (!c || !o || !xo.valid() || !status_out) return LPIPM_ERR_BAD_ARGUMENT;
+    if (c->is_view || !c->halves_env || c->profiling || c->B < 16 || !c->has_problem || c->colsplit)
+        return solve_lockstep_one(c, o, xo, rows, fun_out, its_out, status_out);
+    LP_HIP(hipSetDevice(c->device));
+    if (c->halves.empty()) {
+        const int h = c->B / 2;
+        lpipm_ctx* a = make_view(c, 0, h);
+        lpipm_ctx* b = a ? make_view(c, h, c->B - h) : nullptr;
+        if (!a || !b) {
+            if (a) { c->halves.push_back(a); destroy_views(c); }
+            return solve_lockstep_one(c, o, xo, rows, fun_out, its_out, status_out);
+        }
+        c->halves.push_back(a); c->halves.push_back(b);
+    }
+    LP_HIP(hipStreamSynchronize(c->st));         // the upload (or whatever else the caller enqueued) precedes both halves
+    int rc[2] = {LPIPM_OK, LPIPM_OK};
+    // a view numbers its members from 0: member i of half k is member first + i of the batch
+    std::vector<uint64_t> ident;
+    if (!rows) { ident.resize((size_t)c->B); for (int i = 0; i < c->B; ++i) ident[(size_t)i] = (uint64_t)i; rows = ident.data(); }
+    auto run = [&](int k) {
+        lpipm_ctx* v = c->halves[(size_t)k];
+        const int f = v->bt.first;
+        rc[k] = solve_lockstep_one(v, o, xo, rows + f, fun_out ? fun_out + f : nullptr, its_out ? its_out + f : nullptr, status_out + f);
+    };
+    std::thread other(run, 1);
+    run(0);
+    other.join();
+    return rc[0] != LPIPM_OK ? rc[0] : rc[1];
+}
+
+static int solve_lockstep_one(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, const uint64_t* rows, double* fun_out,
+                              uint64_t* its_out, int32_t* status_out) {
     if (!c || !o || !xo.valid() || !status_out) return LPIPM_ERR_BAD_ARGUMENT;
     if (!(o->alpha0 > 0.0) || !(o->alpha0 < 1.0)) return LPIPM_INVALID_PARAMETER;   // mod.rs:118-128
     if (!(o->tol > 0.0)) return LPIPM_INVALID_PARAMETER;
@@ -1217,7 +1351,7 @@ static int solve_lockstep(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo, con
     for (int i = 0; i < B; ++i) {     // rows[i]: member i's row in the caller's numbering (identity when null)
         if (ret[i] != LPIPM_OK && ret[i] != LPIPM_ITERATION_LIMIT) continue;
         const uint64_t row = rows ? rows[i] : (uint64_t)i;
-        const char* src = (const char*)c->xout + (size_t)i * c->bstride;
+        const char* src = (const char*)c->xout + (size_t)(c->bt.first + i) * c->bstride;
         if (xo.dev) LP_HIP(hipMemcpyAsync(xo.dev + row * xo.stride_bytes, src, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
         else if (xo.host[row]) LP_HIP(hipMemcpyAsync(xo.host[row], src, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
     }

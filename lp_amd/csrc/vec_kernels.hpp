@@ -54,6 +54,7 @@ struct VecArgs {
     double refine_below;  // threshold of skip_refine (refine_below())
     int bcount;       // lockstep batch: LPs per launch (gridDim.z); every pointer above is LP 0's,
     long long bstride;//   LP z's is bstride bytes * z further
+    int bfirst;       // the launch covers the LPs [bfirst, bfirst + bcount) of the resident batch
 };
 
 // n-split mode (a.gs != nullptr): between a vector kernel and the scalar kernel that consumes its

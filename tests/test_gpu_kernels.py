@@ -215,3 +215,33 @@ def test_gemv_dual_one_read_of_A(ctx, m, n):
     oracle.lib().oracle_gemv_t(m, n, p(A), p(v), p(rt))
     assert np.abs(Aw - rn).max() <= 1e-12 * max(1.0, np.abs(rn).max()) * np.sqrt(n)
     assert np.abs(ATv - rt).max() <= 1e-12 * max(1.0, np.abs(rt).max()) * np.sqrt(m)
+
+
+@pytest.mark.parametrize("m,n", [(100, 130), (512, 1024), (640, 3000), (1024, 4096), (1000, 5000), (2048, 9000)])
+def test_adat_units_kernel_single_lp(built, monkeypatch, m, n):
+    """The (tile, chunk) units kernel with its in-launch last-arriver combine (gemm_nt_units_kernel: what lockstep batches and
+    the side-by-side factorisation run) forced onto a single LP (LPIPM_ADAT_UNITS=2): against numpy, bit-identical to the
+    default single-LP kernel up to n = 4096 (one canonical chunking for both), and bit-reproducible over 5 launches (the
+    combine is done by whichever workgroup arrives last: the sums must not depend on who that is)."""
+    import lp_amd
+    from lp_amd import synth
+    A, b, c, _ = synth.planted_lp(3, m, n)
+    d = np.random.default_rng(m + n).uniform(1e-3, 1e3, n)
+    ref = (A * d) @ A.T
+    il = np.tril_indices(m)
+    base = lp_amd.Context(0)
+    base.upload_arrays(A, b, c)
+    M0, _ = base.k_adat(d)
+    base.close()
+    monkeypatch.setenv("LPIPM_ADAT_UNITS", "2")
+    cx = lp_amd.Context(0)
+    monkeypatch.delenv("LPIPM_ADAT_UNITS")
+    cx.upload_arrays(A, b, c)
+    M1, _ = cx.k_adat(d)
+    assert np.abs(M1[il] - ref[il]).max() <= 1e-12 * np.abs(ref).max()
+    if n <= 4096:
+        assert np.array_equal(M1[il], M0[il])
+    for _ in range(5):
+        M2, _ = cx.k_adat(d)
+        assert np.array_equal(M2[il], M1[il])
+    cx.close()
