@@ -477,6 +477,21 @@ int vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr)
     hipLaunchKernelGGL(k_scalar_fun, sgrid(a), dim3(64), 0, st, a);
     return 0;
 }
+// One column group of M (its tiles, in the grouped tile list's order) <-> a contiguous block, for the group-by-group
+// cross-rank sum of the column-split mode.  One workgroup per tile.
+__global__ __launch_bounds__(256) void k_pack_tiles(double* __restrict__ M, long long ld, const int2* __restrict__ tiles,
+                                                    double* __restrict__ P, int dir) {
+    const int2 t = tiles[blockIdx.x];
+    double* m0 = M + (long long)t.x * 128 * ld + (long long)t.y * 128;
+    double2* p = reinterpret_cast<double2*>(P + (long long)blockIdx.x * 16384);
+    for (int e = threadIdx.x; e < 8192; e += 256) {       // 128 rows x 64 pairs
+        double2* q = reinterpret_cast<double2*>(m0 + (long long)(e >> 6) * ld) + (e & 63);
+        if (dir == 0) p[e] = *q; else *q = p[e];
+    }
+}
+void vec_pack_tiles(double* M, long long ld, const int2* tiles, int ntiles, double* packed, int dir, hipStream_t st) {
+    if (ntiles > 0) hipLaunchKernelGGL(k_pack_tiles, dim3(ntiles), dim3(256), 0, st, M, ld, tiles, packed, dir);
+}
 void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st) {
     hipLaunchKernelGGL(k_pack_lower, dim3(mp), dim3(256), 0, st, M, ld, packed, dir);
 }

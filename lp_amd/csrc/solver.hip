@@ -60,6 +60,7 @@ struct lpipm_ctx {
     // A.D.A^T as (tile, chunk) units with an in-launch combine (launch_adat_units; kernels_gemm.hip)
     int units_env = 1;                   // LPIPM_ADAT_UNITS=0: the round-2 kernel (data-parallel tiles + stream-K + fix-up launch)
     bool units = false;                  // this problem runs the units kernel (geometry: the slabs fit the budget)
+    bool grouped_reduce = false;         // column split over ranks: M is reduced group by group behind the running launch
     int cpt = 1, upc = 1;                // chunks per tile, chunks per unit
     int nunits = 0, nunits_grp = 0;
     int2* unit_list = nullptr;           // (tile, first chunk) in dispatch order: chunk-major over the XCD-aware tile order
@@ -134,6 +135,8 @@ struct lpipm_ctx {
     void* coll_user = nullptr;
     bool coll_on_stream = false;  // the callback enqueues the reduction on the ctx's stream itself (no drain before the call)
     double* gs = nullptr;        // 8 doubles: sums / minima that must be reduced across ranks
+    hipStream_t st_c = nullptr;  // communication stream: the column groups of M are packed, reduced and unpacked here, behind the
+    hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;   //   group words of the A.D.A^T launch that is still running on the solver's stream
     double* mpack = nullptr;     // contiguous image of the lower block-triangle of M for its all-reduce
     size_t mpack_count = 0;
 };
@@ -153,11 +156,12 @@ static void drop_graphs(lpipm_ctx* c) {
 // lpipm_set_collective_on_stream(ctx, 1): nothing is drained -- the callee enqueues the reduction ON the stream it is
 // given (ncclAllReduce(..., stream)) and returns at once; stream order does the rest, and the M panels' reduction
 // overlaps whatever the host enqueues next.
-static int ctx_allreduce(lpipm_ctx* c, double* ptr, uint64_t count, int op) {
+static int ctx_allreduce(lpipm_ctx* c, double* ptr, uint64_t count, int op, hipStream_t on = nullptr) {
     if (!c->colsplit || c->world <= 1) return LPIPM_OK;
     if (!c->coll) return LPIPM_ERR_BAD_ARGUMENT;
-    if (!c->coll_on_stream) LP_HIP(hipStreamSynchronize(c->st));
-    if (c->coll(c->coll_user, ptr, count, op, (void*)c->st) != 0) {
+    hipStream_t st = on ? on : c->st;             // (the M groups are reduced on the communication stream, see enqueue_head)
+    if (!c->coll_on_stream) LP_HIP(hipStreamSynchronize(st));
+    if (c->coll(c->coll_user, ptr, count, op, (void*)st) != 0) {
         g_err_detail = "the all-reduce callback of lpipm_set_collective reported a failure";
         return LPIPM_ERR_HIP;
     }
@@ -389,6 +393,9 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (c->tile_list) (void)hipFree(c->tile_list);
     free_list(c->kallocs);
     if (c->mpack) (void)hipFree(c->mpack);
+    if (c->st_c) { (void)hipStreamSynchronize(c->st_c); (void)hipStreamDestroy(c->st_c); }
+    if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
+    if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
     factor_plan_destroy(c->plan);
     factor_plan_destroy(c->kplan);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -508,6 +515,10 @@ static void plan_adat(lpipm_ctx* c, int count) {
     c->cpt = adat_units_cpt(c->npa);
     c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30) &&
                (count > 1 || c->units_env == 2 || c->st_a != nullptr);
+    // one LP split by columns over ranks: the units kernel signals M's column groups one by one, and each group's cross-rank
+    // sum runs behind the rest of the launch (enqueue_head); its slabs may take up to 32 GiB there (C5: 17 GB per rank)
+    if (count == 1 && c->world > 1 && c->units_env != 0 && nt <= 64 * POTRF_OUTER &&
+        (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)32 << 30)) c->units = true;
     // a single LP: one chunk per unit (parallelism, and column groups that complete while the launch runs); a lockstep
     // batch: two chunks per unit -- whole tiles (one unit = all chunks, its own workgroup adds its slabs) leave the last of
     // 2.25 rounds of tiles a quarter full (C4 shard: 1633 LP/s, against 1706 with one chunk per unit, 1533 / 1521 / 1521 at
@@ -627,8 +638,17 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         c->nunits = (int)units.size();
         // Factorisation beside A.D.A^T: single LP, big enough that A.D.A^T can hide the factorisation's chain
         c->overlap = count == 1 && c->st_a != nullptr && mp >= 2048 && c->units && c->cpt > 1 && nt <= 64 * POTRF_OUTER;
+        const bool grouped_reduce = count == 1 && c->world > 1 && c->units && nt <= 64 * POTRF_OUTER;
         std::vector<int2> grouped;
         c->ws_upd_slabs = 0;
+        if (grouped_reduce && !c->overlap) {       // column-group-major unit list for the pipelined reduction of M (enqueue_head)
+            grouped = adat_tile_order_grouped(nt, c->grp_off, c->grp_nt);
+            for (size_t g = 0; g < c->grp_nt.size(); ++g) {
+                std::vector<int> grp((size_t)c->grp_nt[g]);
+                for (int t = 0; t < c->grp_nt[g]; ++t) grp[(size_t)t] = c->grp_off[g] + t;
+                deal_units(grp, c->cpt, 1, units_grp);
+            }
+        }
         if (c->overlap) {
             grouped = adat_tile_order_grouped(nt, c->grp_off, c->grp_nt);
             const int wg_cus = c->num_cu - 8 * c->overlap_cus;
@@ -653,6 +673,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
             }
         }
         c->nunits_grp = (int)units_grp.size();
+        c->grouped_reduce = grouped_reduce && c->nunits_grp > 0;
         Arena measure;
         LP_TRY(layout_problem(c, measure, false));
         c->bstride = round_up(measure.off, 4096);
@@ -927,7 +948,7 @@ static int copy_status(lpipm_ctx* c) {
     if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, (const char*)c->va.status + (size_t)c->bt.first * c->bstride, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
     else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), (const char*)c->va.status + (size_t)c->bt.first * c->bstride, c->bstride,
                                  sizeof(StatusRec), (size_t)c->B, hipMemcpyDeviceToHost, c->st));
-    if (c->factor_in_head)     // a wait kernel of the side-by-side section that gave up (its producer never ran) says so here
+    if (c->factor_in_head || (c->colsplit && c->grouped_reduce))   // a wait kernel that gave up (its producer never ran) says so here
         LP_HIP(hipMemcpyAsync(c->timeout_host, c->wait_timeout, sizeof(unsigned int), hipMemcpyDeviceToHost, c->st));
     return LPIPM_OK;
 }
@@ -953,6 +974,35 @@ static int enqueue_head(lpipm_ctx* c) {
         return LPIPM_OK;
     }
     prof_mark(c, T_VEC, true);
+    if (c->colsplit && c->world > 1 && c->grouped_reduce && c->st_c) {
+        // n-split, M = sum_g A_g D_g A_g^T, PIPELINED: one A.D.A^T launch in column-group-major order on the solver's stream;
+        // the workgroup that completes a group's last tile bumps the group's word; on the communication stream a one-wave
+        // kernel waits for that word, the group's tiles are packed, summed over the ranks (the caller's all-reduce) and
+        // unpacked -- while the launch goes on with the next groups.  After the last tile only the last group's sum is
+        // left (C5: 1/32 .. 1/8 of the 1.08 GB that round 2 reduced in one block after the launch).  Element-wise sums:
+        // the same values as one reduction of the whole triangle.
+        hipStream_t sc = c->st_c;
+        const Batch& bt = c->bt_head;
+        LP_HIP(clear_unit_counters(c, bt, st));
+        LP_HIP(hipEventRecord(c->ev_c0, st));
+        LP_HIP(hipStreamWaitEvent(sc, c->ev_c0, 0));
+        AdatUnitsArgs a = adat_units_args(c, bt);
+        a.tile_list = c->tile_list_grp; a.unit_list = c->unit_list_grp; a.nunits = c->nunits_grp; a.upc = 1;
+        a.grp_cnt = c->grp_cnt; a.C2 = nullptr;
+        LP_HIP(launch_adat_units(a, st));
+        for (size_t g = 0; g < c->grp_nt.size(); ++g) {
+            double* slice = c->mpack + (size_t)c->grp_off[g] * TILE * TILE;
+            LP_HIP(launch_wait_count(c->grp_cnt + g, (unsigned)c->grp_nt[g], bt.done, c->wait_timeout, sc));
+            vec_pack_tiles(c->M, c->mp, c->tile_list_grp + c->grp_off[g], c->grp_nt[g], slice, 0, sc);
+            LP_TRY(ctx_allreduce(c, slice, (uint64_t)c->grp_nt[g] * TILE * TILE, 0, sc));
+            vec_pack_tiles(c->M, c->mp, c->tile_list_grp + c->grp_off[g], c->grp_nt[g], slice, 1, sc);
+        }
+        LP_HIP(hipEventRecord(c->ev_c1, sc));
+        LP_HIP(hipStreamWaitEvent(st, c->ev_c1, 0));
+        if (c->refine > 0) vec_copy_lower(c->M, c->M0, c->mp, c->mp, st, c->bt_head);   // the summed matrix, for the refined solves
+        prof_mark(c, T_ADAT, true);
+        return LPIPM_OK;
+    }
     LP_HIP(run_adat(c, c->bt_head));                                       // newton_equations.rs:55-57
     if (c->colsplit && c->world > 1) {                                     // n-split: M = sum_g A_g D_g A_g^T
         vec_pack_lower(c->M, c->mp, c->mp, c->mpack, 0, st);
@@ -1121,8 +1171,8 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
             prof_collect_overlap(c, c->overlap_sections - (head_out ? 2 : 1));
         }
         ++adat_launches;
-        if (c->factor_in_head && *c->timeout_host != 0) {
-            g_err_detail = "a group of A.D.A^T did not complete within the wait kernel's bound (side-by-side factorisation)";
+        if ((c->factor_in_head || (c->colsplit && c->grouped_reduce)) && *c->timeout_host != 0) {
+            g_err_detail = "a column group of A.D.A^T did not complete within the wait kernel's bound";
             LP_HIP(hipStreamSynchronize(st));
             return LPIPM_ERR_HIP;
         }
@@ -1606,6 +1656,15 @@ extern "C" int lpipm_upload_nsplit(lpipm_ctx* c, uint64_t m, uint64_t n_total, u
             if (c->mpack) { LP_HIP(hipFree(c->mpack)); c->mpack = nullptr; c->mpack_count = 0; }
             LP_HIP(hipMalloc((void**)&c->mpack, need * sizeof(double)));
             c->mpack_count = need;
+        }
+    }
+    if (c->world > 1 && !c->st_c) {
+        if (hipStreamCreateWithFlags(&c->st_c, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->st_c) (void)hipStreamDestroy(c->st_c);
+            c->st_c = nullptr;                   // M is then reduced in one block after the launch
         }
     }
     c->colsplit = true;

@@ -77,6 +77,8 @@ int  vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr
 // packed has mp*(mp+128)/2 doubles; dir 0 = M -> packed, 1 = packed -> M (mp a multiple of 128, ld even)
 void vec_pack_lower(double* M, long long ld, int mp, double* packed, int dir, hipStream_t st);
 void vec_add_rows(int m, int nrhs, double* Y, long long ldy, const double* add0, const double* add1, hipStream_t st);
+// tiles[t] = (ti, tj): packed[t][128][128] <-> the 128 x 128 tile of M at (ti, tj); dir 0 = M -> packed, 1 = packed -> M
+void vec_pack_tiles(double* M, long long ld, const int2* tiles, int ntiles, double* packed, int dir, hipStream_t st);
 // refined Cholesky solve (solver.hip): dst[q][0:mp] = / += src[q][0:mp]; M0 <- lower block-triangle of M
 void vec_rows_copy(int mp, int nrhs, double* dst, const double* src, hipStream_t st, const Batch& bt = Batch{});
 void vec_rows_add(int mp, int nrhs, double* dst, const double* src, hipStream_t st, const Batch& bt = Batch{});

@@ -153,3 +153,63 @@ def test_bench_distributed_code_path_on_one_rank(built):
         assert out.returncode == 0, out.stderr[-2000:]
         r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert r["n_gpus"] == 1 and r["value"] > 0
+
+
+def _worker_two_ways(rank, world, port, q, seed, m, n):
+    """The same column-split solve twice: group-by-group reduction of M behind the running A.D.A^T launch (default) and the
+    one-block reduction after it (LPIPM_ADAT_UNITS=0: the round-2 path)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import lp_amd
+    from lp_amd import synth
+    from lp_amd.colsplit import column_range, solve_column_split
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b, c = synth.planted_lp(seed, m, n)[:3]
+    cols = column_range(n, world, rank, 128)
+    opts = lp_amd.InteriorPoint.default().opts()
+    out = []
+    for env in (None, "0"):
+        if env is not None:
+            os.environ["LPIPM_ADAT_UNITS"] = env
+        ctx = lp_amd.Context(0)
+        os.environ.pop("LPIPM_ADAT_UNITS", None)
+        rc, x, fun, it, rows, coll = solve_column_split(np.ascontiguousarray(A[:, cols.start:cols.stop]), b, c[cols.start:cols.stop], n,
+                                                        0.0, opts, ctx=ctx, want_log=True)
+        out.append((rc, x.tolist(), fun, it, coll.calls))
+        ctx.close()
+    q.put((rank, cols.start, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_group_by_group_reduction_of_M_is_bit_identical_to_the_one_block_reduction(built):
+    """m = 1536 (12 tile rows = 3 column groups of the normal equations), two ranks: the groups of M are summed over the
+    ranks one by one on the communication stream while the A.D.A^T launch is still producing the later ones
+    (solver.hip enqueue_head, lpipm_ctx::grouped_reduce).  An element-wise sum of two terms: the same bits as reducing
+    the whole packed triangle in one block after the launch, and more collective calls (one per group and iteration)."""
+    import torch.multiprocessing as mp
+    from lp_amd import synth
+    from oracle import capi as oracle
+    world, seed, m, n = 2, 5, 1536, 3072
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 29500 + (os.getpid() * 7 + 977) % 2000
+    procs = [mpc.Process(target=_worker_two_ways, args=(r, world, port, q, seed, m, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A, b, c = synth.planted_lp(seed, m, n)[:3]
+    ref = oracle.solve(A, b, c)
+    x = np.full(n, np.nan)
+    for rank, lo, (grouped, block) in got:
+        assert grouped[0] == block[0] == 0 and grouped[3] == block[3] == ref["iterations"]
+        assert grouped[1] == block[1] and grouped[2] == block[2]          # bit-identical x and objective
+        assert grouped[4] == block[4] + 2 * grouped[3]                      # 3 groups instead of 1 block per iteration
+        x[lo:lo + len(grouped[1])] = grouped[1]
+    assert np.abs(x - ref["x_slack"]).max() <= 1e-6
