@@ -273,7 +273,7 @@ def measure_single(m, n, steps, warmup, c2, want_cpu_baseline, rank, local_rank,
     traffic = None
     mfma_busy = None
     pmc_note = "no PMC summary for this workload"
-    pmc_path = os.path.join(ROOT, "profiles", "r02_gemv_pmc.json" if c2 else "r02_adat_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_gemv_pmc.json" if c2 else "r03_adat_pmc.json")
     if (m, n) in ((4096, 8192), (512, 1024)) and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         if pmc.get("csrc_sha256") == csrc_hash():

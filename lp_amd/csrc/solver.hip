@@ -525,7 +525,6 @@ static void plan_adat(lpipm_ctx* c, int count) {
     // 2 / 1 / 4 chunks on a slower box)
     c->upc = count == 1 ? 1 : (c->cpt < 2 ? c->cpt : 2);
     { int kc, nbig, ks; if (adat_units_chunking(c->npa, &kc, &nbig, &ks) != nbig) c->upc = 1; }   // non-uniform chunks: one per unit
-    if (const char* e = getenv("LPIPM_ADAT_UPC")) { const int v = atoi(e); if (v >= 1) c->upc = v < c->cpt ? v : c->cpt; }   // measurement knob
     if (c->units && c->ws_slabs < (size_t)c->ntiles * c->cpt) c->ws_slabs = (size_t)c->ntiles * c->cpt;
 }
 

@@ -33,7 +33,9 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     res["fetch_correction"] = ("x2: on gfx950 FETCH_SIZE reports 1/2 of the bytes of 16-B-per-lane coalesced loads "
                                "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact")
     res["traffic_bytes_per_launch"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
-    res["algorithmic_bytes_per_launch"] = 8 * m * n + (4 * m * m if "streamk" in kern else 0)
+    nlp = int(os.environ.get("PMC_LPS_PER_LAUNCH", "32" if "units" in kern else "1"))     # a lockstep launch covers the whole batch
+    res["algorithmic_bytes_per_launch"] = nlp * (8 * m * n + (4 * m * m if ("streamk" in kern or "units" in kern) else 0))
+    res["lps_per_launch"] = nlp
     res["note"] = ("FETCH_SIZE counts L2->fabric requests; Infinity-Cache (256 MiB) hits are included, so this is an upper "
                    "bound on HBM bytes.")
 if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
