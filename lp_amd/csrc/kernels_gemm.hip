@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void gemm_nt_fixup_kernel(const GemmK p0) {
 //   one running sum 5.5e-7 | 1024 columns 2.27 ms, 1.2e-7 | 512 columns 2.34 ms, 7.9e-8 | 256 columns 2.55 ms, 6.3e-8
 // (the oracle itself: 6.3e-8).  LPIPM_ADAT_KC=<k-tiles> overrides the rule (measurement knob).
 int gemm_streamk_chunk(int KT) {
-    static const int forced = getenv("LPIPM_ADAT_KC") ? atoi(getenv("LPIPM_ADAT_KC")) : -1;
+    static const int forced = lp_knob("LPIPM_ADAT_KC") ? atoi(lp_knob("LPIPM_ADAT_KC")) : -1;
     if (forced >= 0) return forced == 0 ? (KT > 0 ? KT : 1) : forced;
     return KT <= 64 ? 8 : (KT <= 256 ? 16 : 64);
 }
@@ -887,7 +887,7 @@ int gemm_streamk_chunk(int KT) {
 // finer blocks than the data-parallel ones (same determinism, the decomposition-independence is given up for big LPs).
 static int streamk_unit(int KT) {
     const int kc = gemm_streamk_chunk(KT);
-    static const int forced = getenv("LPIPM_ADAT_SK") ? atoi(getenv("LPIPM_ADAT_SK")) : 0;   // measurement knob
+    static const int forced = lp_knob("LPIPM_ADAT_SK") ? atoi(lp_knob("LPIPM_ADAT_SK")) : 0;   // measurement knob
     if (forced > 0 && KT > 256) return forced;
     return KT <= 256 ? kc : (kc < 16 ? kc : 16);
 }

@@ -438,7 +438,7 @@ static int cross(const VecArgs& a, const XRank* xr, int first, int count, int is
     return xr->fn(xr->self, a.gs + red_first, red_count, is_min);
 }
 double refine_below() {
-    static const double v = getenv("LPIPM_REFINE_BELOW") ? atof(getenv("LPIPM_REFINE_BELOW")) : REFINE_BELOW_RHO_MU;
+    static const double v = lp_knob("LPIPM_REFINE_BELOW") ? atof(lp_knob("LPIPM_REFINE_BELOW")) : REFINE_BELOW_RHO_MU;
     return v;
 }
 int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr) {

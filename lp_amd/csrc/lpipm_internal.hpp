@@ -17,6 +17,13 @@ constexpr int NB   = 128;  // Cholesky / TRSV block size (== TILE)
 
 inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 
+// ---------------------------------------------------------------- measurement knobs
+// Every LPIPM_* environment variable the library reads is a MEASUREMENT knob (kernel variants, schedules, widths: several
+// of them change the bits of a result).  They are read through this one function, which ignores them unless
+// LPIPM_EXPERIMENTAL=1 is set as well: a stray variable in a production (or parity-test) environment cannot change what the
+// library computes.  tests/conftest.py refuses to run with LPIPM_EXPERIMENTAL set; tests that exercise a knob set both.
+const char* lp_knob(const char* name);
+
 // ---------------------------------------------------------------- error plumbing
 void set_error_detail(const char* what, hipError_t e, const char* file, int line);
 #define LP_HIP(expr)                                                        \

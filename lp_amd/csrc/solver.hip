@@ -34,6 +34,12 @@ void set_error_detail(const char* what, hipError_t e, const char* file, int line
 }  // namespace lpipm
 
 namespace lpipm { extern long long* g_diag_stamps; }
+namespace lpipm {
+const char* lp_knob(const char* name) {
+    const char* master = getenv("LPIPM_EXPERIMENTAL");
+    return (master && master[0] == '1') ? getenv(name) : nullptr;
+}
+}  // namespace lpipm
 enum { T_VEC = 0, T_ADAT, T_POTRF, T_TRSV, T_GEMV, T_NTAGS };
 
 struct lpipm_ctx {
@@ -305,13 +311,13 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     c->status_cap = 1;
     // LPIPM_REFINE (see lpipm_ctx::refine) is read ONCE, here: the arena layout depends on it (M0, R0, Rho and the symv slabs
     // exist only for a refining context: 134 MB at C3, 2 GB at m = 16384, per member of a lockstep batch)
-    { const char* e = getenv("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
+    { const char* e = lp_knob("LPIPM_REFINE"); c->refine = !e ? 0 : (e[0] == '2' ? 2 : (e[0] == '1' ? 1 : 0)); }
     // LPIPM_ADAT_UNITS: 0 = the round-2 kernel everywhere, 2 = the units kernel for single LPs too (measurement / test knob);
     // default 1 = units kernel for lockstep batches and for the side-by-side factorisation, round-2 kernel for a single LP
     // (measured per launch, units vs round-2: 512x1024 0.042 / 0.045 ms, 1024x2048 0.102 / 0.097, 2048x4096 0.469 / 0.458,
     // 4096x8192 2.47 / 2.39 standalone and 2.32 / 2.25 inside a solve; C4 lockstep shard 1732 vs 1674 LP/s)
-    { const char* e = getenv("LPIPM_ADAT_UNITS"); c->units_env = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }
-    { const char* e = getenv("LPIPM_HALVES"); c->halves_env = (e && e[0] == '0') ? 0 : 1; }
+    { const char* e = lp_knob("LPIPM_ADAT_UNITS"); c->units_env = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }
+    { const char* e = lp_knob("LPIPM_HALVES"); c->halves_env = (e && e[0] == '0') ? 0 : 1; }
     if (hipHostMalloc((void**)&c->timeout_host, sizeof(unsigned int)) != hipSuccess) {
         g_err_detail = "failed to allocate the pinned time-out word";
         lpipm_destroy(c);
@@ -325,9 +331,9 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     // beside it) the rest.  LPIPM_OVERLAP=0 switches the scheme off, LPIPM_OVERLAP_CUS=R sets R (default 4).  Only on the
     // 8 x 32 CU layout it was measured on.
     {
-        const char* on = getenv("LPIPM_OVERLAP");
+        const char* on = lp_knob("LPIPM_OVERLAP");
         int R = 4;
-        if (const char* e = getenv("LPIPM_OVERLAP_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 16) R = v; }
+        if (const char* e = lp_knob("LPIPM_OVERLAP_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 16) R = v; }
         if (OVERLAP_DEFAULT ? !(on && on[0] == '0') : (on && on[0] == '1')) if (c->num_cu == 256 && c->units_env) {
             uint32_t ma[8], mb[8];
             for (int w = 0; w < 8; ++w) { ma[w] = 0; mb[w] = 0; }
@@ -352,9 +358,9 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     // stream's kernels -- the diagonal-block kernel needs a CU to itself (150 KB of LDS) and would otherwise wait for a
     // side-stream tile to drain.  LPIPM_LOOKAHEAD_CUS=R sets R (default 8; 0: an unmasked low-priority stream).
     {
-        const char* on = getenv("LPIPM_LOOKAHEAD");
+        const char* on = lp_knob("LPIPM_LOOKAHEAD");
         int R = 8;
-        if (const char* e = getenv("LPIPM_LOOKAHEAD_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 16) R = v; }
+        if (const char* e = lp_knob("LPIPM_LOOKAHEAD_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 16) R = v; }
         if (on && on[0] == '1' && c->num_cu == 256) {
             uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < 256; ++i) if ((i / 8) >= R) mk[i / 32] |= 1u << (i % 32);
@@ -461,13 +467,13 @@ static std::vector<int2> adat_tile_order(int nt) {
 // inverse (1024) costs a flop-bound batch more than the two solve steps it saves, and a single small LP about as much
 // as it gains.  LPIPM_SUPER=<multiple of 128> overrides it (measurement knob).
 static int super_for(int mp) {
-    if (const char* e = getenv("LPIPM_SUPER")) { const int w = atoi(e); if (w >= NB && w % NB == 0 && w <= 4096) return w; }
+    if (const char* e = lp_knob("LPIPM_SUPER")) { const int w = atoi(e); if (w >= NB && w % NB == 0 && w <= 4096) return w; }
     return mp <= 2048 ? 512 : SUPER;
 }
 static int merge_edge_for(int) {
     // 32x32 merge tiles: a stage is one round of tiles on the chain (factorisation m = 512: 194 -> 177 us, 1024: 364 -> 346,
     // 4096: 1865 -> 1854; the lockstep C4 batch is indifferent: 1745 LP/s either way)
-    if (const char* e = getenv("LPIPM_MERGE_EDGE")) { const int v = atoi(e); return (v == 128 || v == 64) ? v : 32; }
+    if (const char* e = lp_knob("LPIPM_MERGE_EDGE")) { const int v = atoi(e); return (v == 128 || v == 64) ? v : 32; }
     return 32;
 }
 
@@ -1120,9 +1126,9 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     VecArgs& v = c->va;
     hipStream_t st = c->st;
     if (c->use_graph < 0) {   // measurement knobs: LPIPM_GRAPH=1 (hipGraph replay), LPIPM_SPECULATE=0 (no early head)
-        const char* g = getenv("LPIPM_GRAPH");
+        const char* g = lp_knob("LPIPM_GRAPH");
         c->use_graph = (g && g[0] == '1') ? 1 : 0;
-        const char* sp = getenv("LPIPM_SPECULATE");
+        const char* sp = lp_knob("LPIPM_SPECULATE");
         c->no_speculate = sp && sp[0] == '0';
     }
     c->factor_in_head = c->overlap && !c->colsplit && c->use_graph != 1 && o->solver_type == LPIPM_SOLVER_CHOLESKY;
@@ -1765,7 +1771,7 @@ extern "C" int lpipm_k_potrf(lpipm_ctx* c, uint64_t m, double* M_inout, int32_t*
         total += ms;
     }
     if (ms_out) *ms_out = total / repeats;
-    if (getenv("LPIPM_DIAG_STAMPS")) {  // debug aid: cycle stamps of the first diagonal-block kernel
+    if (lp_knob("LPIPM_DIAG_STAMPS")) {  // debug aid: cycle stamps of the first diagonal-block kernel
         long long* d = nullptr; long long h[64] = {0};
         if (hipMalloc((void**)&d, sizeof(h)) == hipSuccess) {
             g_diag_stamps = d;

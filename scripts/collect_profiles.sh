@@ -14,14 +14,14 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p_bench -o bench --output-format csv -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --only-headline > $OUT/${R}_bench_profiled.json 2> /tmp/p_bench.log
 cp /tmp/p_bench/bench_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 echo "kernel stats of the headline done"
-LPIPM_HALVES=0 rocprofv3 --kernel-trace --stats -d /tmp/p_c4 -o c4 --output-format csv -- python3 $REPO/scripts/lockstep_c4.py 32 1024 2048 5 > $OUT/${R}_c4_lockstep_profiled.txt 2> /tmp/p_c4.log
+LPIPM_EXPERIMENTAL=1 LPIPM_HALVES=0 rocprofv3 --kernel-trace --stats -d /tmp/p_c4 -o c4 --output-format csv -- python3 $REPO/scripts/lockstep_c4.py 32 1024 2048 5 > $OUT/${R}_c4_lockstep_profiled.txt 2> /tmp/p_c4.log
 cp /tmp/p_c4/c4_kernel_stats.csv $OUT/${R}_c4_lockstep_kernel_stats.csv
 echo "kernel stats of the lockstep shard done"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   tag=$(echo $grp | cut -d" " -f1)
   rocprofv3 --pmc $grp -d /tmp/p_pmc_c3/$tag -o pmc --output-format csv -- python3 $REPO/scripts/prof_c3.py > /tmp/p_pmc_$tag.log 2>&1
   rocprofv3 --pmc $grp -d /tmp/p_pmc_c2/$tag -o pmc --output-format csv -- python3 $REPO/scripts/prof_c3.py 512 1024 > /tmp/p_pmc2_$tag.log 2>&1
-  LPIPM_HALVES=0 rocprofv3 --pmc $grp -d /tmp/p_pmc_c4/$tag -o pmc --output-format csv -- python3 $REPO/scripts/lockstep_c4.py 32 1024 2048 2 > /tmp/p_pmc4_$tag.log 2>&1
+  LPIPM_EXPERIMENTAL=1 LPIPM_HALVES=0 rocprofv3 --pmc $grp -d /tmp/p_pmc_c4/$tag -o pmc --output-format csv -- python3 $REPO/scripts/lockstep_c4.py 32 1024 2048 2 > /tmp/p_pmc4_$tag.log 2>&1
   echo "pmc pass $tag done"
 done
 cd $REPO

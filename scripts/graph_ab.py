@@ -18,5 +18,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ctx.close()
 else:
     for g, sp in (("0", "0"), ("1", "1"), ("0", "1")):
-        env = dict(os.environ, LPIPM_GRAPH=g, LPIPM_SPECULATE=sp)
+        env = dict(os.environ, LPIPM_EXPERIMENTAL="1", LPIPM_GRAPH=g, LPIPM_SPECULATE=sp)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)

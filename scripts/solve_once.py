@@ -1,5 +1,6 @@
 """A few solves of one planted LP (for rocprofv3 traces): solve_once.py m n reps  (environment knobs apply)."""
 import os, sys
+os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lp_amd as lp

@@ -11,9 +11,10 @@ if ROOT not in sys.path:
 # Environment knobs of liblpipm.so that CHANGE THE BITS of a result (summation chunking, super-block width, refinement,
 # tile edges, schedules): parity is claimed for the library's defaults only, so none of them may leak in from the
 # environment the suite runs in.  (Tests that exercise a knob set it themselves with monkeypatch, after this check.)
-BIT_CHANGING_KNOBS = ("LPIPM_ADAT_KC", "LPIPM_ADAT_SK", "LPIPM_SUPER", "LPIPM_REFINE", "LPIPM_REFINE_BELOW",
+# The library ignores every one of them unless the master switch LPIPM_EXPERIMENTAL=1 is set (lp_knob, lpipm_internal.hpp).
+BIT_CHANGING_KNOBS = ("LPIPM_EXPERIMENTAL", "LPIPM_ADAT_KC", "LPIPM_ADAT_SK", "LPIPM_SUPER", "LPIPM_REFINE", "LPIPM_REFINE_BELOW",
                       "LPIPM_MERGE_EDGE", "LPIPM_OVERLAP", "LPIPM_OVERLAP_CUS", "LPIPM_LOOKAHEAD", "LPIPM_LOOKAHEAD_CUS",
-                      "LPIPM_GRAPH", "LPIPM_SPECULATE", "LPIPM_HALVES", "LPIPM_ADAT_GROUPED")
+                      "LPIPM_GRAPH", "LPIPM_SPECULATE", "LPIPM_HALVES", "LPIPM_ADAT_UNITS")
 
 
 def pytest_configure(config):

@@ -173,9 +173,11 @@ def _worker_two_ways(rank, world, port, q, seed, m, n):
     out = []
     for env in (None, "0"):
         if env is not None:
+            os.environ["LPIPM_EXPERIMENTAL"] = "1"          # knobs are read only with the master switch on
             os.environ["LPIPM_ADAT_UNITS"] = env
         ctx = lp_amd.Context(0)
         os.environ.pop("LPIPM_ADAT_UNITS", None)
+        os.environ.pop("LPIPM_EXPERIMENTAL", None)
         rc, x, fun, it, rows, coll = solve_column_split(np.ascontiguousarray(A[:, cols.start:cols.stop]), b, c[cols.start:cols.stop], n,
                                                         0.0, opts, ctx=ctx, want_log=True)
         out.append((rc, x.tolist(), fun, it, coll.calls))

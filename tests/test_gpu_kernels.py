@@ -111,6 +111,7 @@ def test_potrf_lookahead_is_bit_identical(built, monkeypatch):
     serial = lp_amd.Context(0)
     L0, info0, _ = serial.k_potrf(M)
     serial.close()
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
     monkeypatch.setenv("LPIPM_LOOKAHEAD", "1")
     ahead = lp_amd.Context(0)
     for _ in range(3):
@@ -233,9 +234,11 @@ def test_adat_units_kernel_single_lp(built, monkeypatch, m, n):
     base.upload_arrays(A, b, c)
     M0, _ = base.k_adat(d)
     base.close()
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
     monkeypatch.setenv("LPIPM_ADAT_UNITS", "2")
     cx = lp_amd.Context(0)
     monkeypatch.delenv("LPIPM_ADAT_UNITS")
+    monkeypatch.delenv("LPIPM_EXPERIMENTAL")
     cx.upload_arrays(A, b, c)
     M1, _ = cx.k_adat(d)
     assert np.abs(M1[il] - ref[il]).max() <= 1e-12 * np.abs(ref).max()

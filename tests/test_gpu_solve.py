@@ -381,6 +381,7 @@ def test_graph_replay_is_bit_identical(built, monkeypatch):
     plain.upload_arrays(A, b, c)
     r0 = plain.solve_raw(o, want_log=True)
     plain.close()
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
     monkeypatch.setenv("LPIPM_GRAPH", "1")
     g = lp_amd.Context(0)
     g.upload_arrays(A, b, c)
@@ -519,6 +520,7 @@ def test_factorisation_beside_adat_matches_golden(built, monkeypatch):
     from lp_amd import synth
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "planted_4096x8192_s1.npz"))
     A, b, c, _ = synth.planted_lp(1, 4096, 8192)
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
     monkeypatch.setenv("LPIPM_OVERLAP", "1")
     ctx = lp.Context(0)                       # the streams are created with the context
     ctx.upload_arrays(A, b, c)
