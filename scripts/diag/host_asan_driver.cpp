@@ -17,7 +17,7 @@ static LP make(uint64_t seed, uint64_t m, uint64_t n) {
 static double maxerr(const std::vector<double>& x, const std::vector<double>& y) {
     double e = 0; for (size_t i = 0; i < x.size(); ++i) e = std::fmax(e, std::fabs(x[i] - y[i])); return e;
 }
-#define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+#define CHECK(cond) do { if (!(cond)) { printf("FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, lpipm_last_error_detail()); fflush(stdout); _exit(1); } } while (0)
 
 int main() {
     lpipm_ctx* ctx = nullptr;
@@ -53,6 +53,26 @@ int main() {
     CHECK(lpipm_upload_lockstep(ctx, 7, 96, 200, A.data(), b.data(), c.data(), nullptr) == 0);
     CHECK(lpipm_solve_lockstep(ctx, &o, xp.data(), fun.data(), its.data(), st.data()) == 0);
     for (int i = 0; i < 7; ++i) CHECK(st[i] == 0);
+    // a lockstep batch large enough for the two half-batch views (two host threads, shared arenas), then a smaller one again
+    // (the views are torn down at the upload), then the large one twice in a row (views reused)
+    {
+        std::vector<LP> big;
+        for (int s = 0; s < 18; ++s) big.push_back(make(100 + s, 96, 200));
+        std::vector<const double*> A2(18), b2(18), c2v(18);
+        std::vector<std::vector<double>> x2(18, std::vector<double>(200));
+        std::vector<double*> xp2(18);
+        std::vector<double> fun2(18); std::vector<uint64_t> its2(18); std::vector<int32_t> st2(18);
+        for (int i = 0; i < 18; ++i) { A2[i] = big[i].A.data(); b2[i] = big[i].b.data(); c2v[i] = big[i].c.data(); xp2[i] = x2[i].data(); }
+        for (int round = 0; round < 2; ++round) {
+            CHECK(lpipm_upload_lockstep(ctx, 18, 96, 200, A2.data(), b2.data(), c2v.data(), nullptr) == 0);
+            for (int rep = 0; rep < 2; ++rep) {
+                CHECK(lpipm_solve_lockstep(ctx, &o, xp2.data(), fun2.data(), its2.data(), st2.data()) == 0);
+                for (int i = 0; i < 18; ++i) { CHECK(st2[i] == 0); CHECK(maxerr(x2[i], big[i].xs) < 1e-5); }
+            }
+            CHECK(lpipm_upload_lockstep(ctx, 7, 96, 200, A.data(), b.data(), c.data(), nullptr) == 0);
+            CHECK(lpipm_solve_lockstep(ctx, &o, xp.data(), fun.data(), its.data(), st.data()) == 0);
+        }
+    }
     // ub / eq upload (README LP: known answer [1, 0])
     const double c2[2] = {-1, 4}, Aub[4] = {-3, 1, 1, 2}, bub[2] = {6, 4}, Aeq[2] = {1, 1}, beq[1] = {1};
     CHECK(lpipm_upload_ub_eq(ctx, 2, 2, Aub, 2, bub, 1, Aeq, 2, beq, c2, 0.0) == 0);
@@ -83,6 +103,7 @@ int main() {
     lpipm_destroy(ctx);
     // refined solves (LPIPM_REFINE=2) and the factorisation beside A.D.A^T (LPIPM_OVERLAP=1): both are decided when a
     // context is created / first solves
+    setenv("LPIPM_EXPERIMENTAL", "1", 1);     // the library reads its measurement knobs only with the master switch on
     setenv("LPIPM_REFINE", "2", 1);
     setenv("LPIPM_OVERLAP", "1", 1);
     {
