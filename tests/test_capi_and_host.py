@@ -132,3 +132,22 @@ def test_product_never_imports_oracle():
                                 or "liboracle" in s:
                             bad.append((fn, s))
     assert not bad, bad
+
+
+def test_units_kernel_has_no_spills_and_four_waves_per_simd():
+    """Build-time property of the A.D.A^T units kernel (kernels_gemm.hip, gemm_nt_units_kernel): 4 waves per SIMD (two
+    512-thread workgroups per CU) with NO VGPR / SGPR spill and no scratch -- at 128 VGPRs a spill inside the main loop puts
+    an s_waitcnt vmcnt(0) in front of the prefetch it has just issued.  Read from hipcc's own resource-usage remarks."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "lp_amd", "csrc", "kernels_gemm.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "--cuda-device-only", "-c",
+                          "-Rpass-analysis=kernel-resource-usage", src, "-o", os.devnull],
+                         capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
+    blocks = re.split(r"remark: Function Name: ", out)
+    units = [b for b in blocks if "gemm_nt_units_kernel" in b.splitlines()[0]]
+    assert len(units) == 2, [b.splitlines()[0] for b in blocks[1:]]          # <GRP = false>, <GRP = true>
+    for b in units:
+        get = lambda key: int(re.search(key + r": (\d+)", b).group(1))
+        assert get(r"VGPRs Spill") == 0 and get(r"SGPRs Spill") == 0 and get(r"ScratchSize \[bytes/lane\]") == 0, b
+        assert get(r"Occupancy \[waves/SIMD\]") == 4 and get(r"VGPRs") <= 128, b
