@@ -1,8 +1,8 @@
 """A.D.A^T kernel variants and the side-by-side factorisation, on the GPU box:
    python scripts/adat_variants.py            -> per-launch ms of k_adat (units kernel vs round-2 kernel, bit comparison),
                                                  solve it/s at C3 with LPIPM_OVERLAP on/off, C4 lockstep LP/s both kernels."""
-import os, sys
-os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on, time
+import os, sys, time
+os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lp_amd as lp

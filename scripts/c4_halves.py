@@ -1,7 +1,8 @@
 """C4 shard (32 x 1024x2048) as ONE lockstep batch of 32 vs TWO lockstep batches of 16 solved concurrently from two host
 threads (own context, own stream each): does the hardware overlap one half's A.D.A^T with the other half's chain?"""
-import os, sys
-os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on, time, threading
+import os, sys, time
+os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on
+import threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lp_amd as lp

@@ -1,6 +1,6 @@
 """C4 shard (32 x 1024x2048 lockstep) under the environment given on the command line; prints LP/s and the phase split."""
-import os, sys
-os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on, time
+import os, sys, time
+os.environ["LPIPM_EXPERIMENTAL"] = "1"      # the library reads its measurement knobs only with the master switch on
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lp_amd as lp
