@@ -61,6 +61,11 @@ extern "C" {
         ctx: *mut lpipm_ctx, opts: *const lpipm_opts, x_slack_out: *mut f64, fun_out: *mut f64,
         iterations_out: *mut u64, log: *mut lpipm_iter_row,
     ) -> c_int;
+    /// InteriorPoint<f32> (src/float.rs:42-43): the same algorithm with every operation in f32; upload + solve in one call
+    pub fn lpipm_solve_f32(
+        ctx: *mut lpipm_ctx, m: u64, n: u64, a: *const f32, lda: u64, b: *const f32, c: *const f32, c0: f32,
+        opts: *const lpipm_opts, x_slack_out: *mut f32, fun_out: *mut f32, iterations_out: *mut u64, log: *mut c_void,
+    ) -> c_int;
     pub fn lpipm_strerror(status: c_int) -> *const c_char;
     pub fn lpipm_last_error_detail() -> *const c_char;
 

@@ -60,6 +60,8 @@ typedef struct {
 
 /* One row of the `disp` table: alpha (mod.rs:228) + Indicators (indicators.rs:8-23). */
 typedef struct { double alpha, rho_p, rho_d, rho_A, rho_g, rho_mu, obj; } lpipm_iter_row;
+/* The same row of an f32 solve (lpipm_solve_f32). */
+typedef struct { float alpha, rho_p, rho_d, rho_A, rho_g, rho_mu, obj; } lpipm_iter_row_f32;
 
 /* Device time per phase of the LAST lpipm_solve on this ctx, from HIP events on the ctx's stream
  * (only filled while profiling is on; recording events costs a few us per phase). */
@@ -247,6 +249,25 @@ int lpipm_k_iteration(lpipm_ctx* ctx, const lpipm_opts* opts, int ip, double* x,
 /* residual.rs:23,25 / feasible_point.rs:122-123 in ONE read of A: Aw_out[m] = A.w, ATv_out[n] = A^T.v (w[n], v[m]). */
 int lpipm_k_gemv_dual(lpipm_ctx* ctx, const double* w, const double* v, double* Aw_out, double* ATv_out, int repeats,
                       double* ms_out);
+/* ---- InteriorPoint<f32> ------------------------------------------------------------------------
+ * src/float.rs:42-43 (`impl Float for f32`): the reference's solver is generic over F; with F = f32 every operation of
+ * interior_point/mod.rs:161-168, :199-240 runs in f32.  lpipm_solve_f32 is that instantiation: the same algorithm as
+ * lpipm_solve with every operation in f32, on generic (scalar-type-templated) HIP kernels -- correctness first, like the
+ * QR arms; the hand-written fp64 path is the fast one.  The slack-form problem (A m x n row-major, lda >= n) is uploaded,
+ * solved and released inside the call.  opts: tol and alpha0 are converted to f32; only the Cholesky arm (the default).
+ * Return codes as lpipm_solve; x_slack_out[n] = x / tau (also for LPIPM_ITERATION_LIMIT); log nullable, max_iter rows.
+ * NOTE (reference behaviour, not a property of this backend): with the default tol = 1e-8 an f32 solve cannot satisfy the
+ * optimality test (f32 epsilon is 6e-8): it ends in IterationLimitExceeded or NumericalProblem; pass a tolerance f32 can
+ * reach (1e-4 .. 1e-5). */
+int lpipm_solve_f32(lpipm_ctx* ctx, uint64_t m, uint64_t n, const float* A_rowmajor, uint64_t lda, const float* b,
+                    const float* c, float c0, const lpipm_opts* opts, float* x_slack_out, float* fun_out,
+                    uint64_t* iterations_out, lpipm_iter_row_f32* log);
+/* Test hook: the SAME generic kernels instantiated for double (solver_generic.hip), so that they can be checked against
+ * the fp64 oracle to 1e-8 -- which f32 arithmetic itself cannot show. */
+int lpipm_k_generic_solve_f64(lpipm_ctx* ctx, uint64_t m, uint64_t n, const double* A_rowmajor, uint64_t lda, const double* b,
+                              const double* c, double c0, const lpipm_opts* opts, double* x_slack_out, double* fun_out,
+                              uint64_t* iterations_out, lpipm_iter_row* log);
+
 /* fp64 MFMA issue-rate probe (v_mfma_f64_16x16x4_f64 back to back, operands in registers):
  * tflops_out = achieved TFLOP/s over the whole chip; used to confirm the roofline denominator. */
 int lpipm_k_mfma_f64_probe(lpipm_ctx* ctx, int iters, double* tflops_out, double* ms_out);

@@ -107,8 +107,12 @@ def _f64(a):
 class Problem:
     """A linear program in slack form (linear_program.rs:24-30): min c'x st A x == b, x >= 0."""
 
-    def __init__(self, A, b, c, c0, n_slack, parts=None):
+    def __init__(self, A, b, c, c0, n_slack, parts=None, dtype=np.float64):
         self._A, self._b, self._c, self._c0, self._n_slack = A, b, c, float(c0), int(n_slack)
+        # F of Problem<F> (linear_program.rs:24): float32 when every array the builder was given is float32 (the reference
+        # infers F from its ndarray arguments), float64 otherwise.  A Problem<f32> is solved by InteriorPoint<f32>
+        # (lpipm_solve_f32: every operation in f32, src/float.rs:42-43).
+        self.dtype = np.dtype(dtype)
         # the `ub` / `eq` blocks the builder was given: (A_ub, b_ub, A_eq, b_eq, c).  With them the slack-form matrix
         # is assembled on the device (lpipm_upload_ub_eq) and the host copy below exists only if A() is asked for.
         self._parts = parts
@@ -121,7 +125,7 @@ class Problem:
         if self._A is None:                      # lazily: [[A_ub, I], [A_eq, 0]] (:145-156)
             A_ub, _, A_eq, _, c = self._parts
             m_ub, m_eq, n = A_ub.shape[0], A_eq.shape[0], c.shape[0]
-            A = np.zeros((m_ub + m_eq, n + m_ub))
+            A = np.zeros((m_ub + m_eq, n + m_ub), dtype=self.dtype)
             A[:m_ub, :n] = A_ub
             A[m_ub:, :n] = A_eq
             A[np.arange(m_ub), n + np.arange(m_ub)] = 1.0
@@ -161,6 +165,8 @@ class ProblemBuilder:
         return self
 
     def build(self) -> Problem:                  # :125-169
+        given = [self._c] + [a for pair in (self._ub, self._eq) if pair is not None for a in pair]
+        f32 = all(isinstance(a, np.ndarray) and a.dtype == np.float32 for a in given)
         c = _f64(self._c)
         if c.ndim != 1:
             raise IncompatibleInputDimensions()
@@ -178,6 +184,10 @@ class ProblemBuilder:
             raise IncompatibleInputDimensions()
         b = np.concatenate([b_ub, b_eq])                                     # :157-158
         cs = np.concatenate([c, np.zeros(m_ub)])                             # :159-160
+        if f32:     # Problem<f32>: the f32 values as given (exactly representable in the f64 working copies above)
+            t = np.float32
+            return Problem(None, b.astype(t), cs.astype(t), 0.0, m_ub,
+                           parts=(A_ub.astype(t), b_ub.astype(t), A_eq.astype(t), b_eq.astype(t), c.astype(t)), dtype=t)
         return Problem(None, b, cs, 0.0, m_ub, parts=(A_ub, b_ub, A_eq, b_eq, c))   # :161; A on demand
 
 
@@ -391,6 +401,40 @@ class Context:
                 rows.append((r.alpha, r.rho_p, r.rho_d, r.rho_A, r.rho_g, r.rho_mu, r.obj))
         return rc, x, fun.value, int(it.value), rows
 
+    def solve_f32(self, A, b, c, c0: float = 0.0, opts: "_capi.Opts | None" = None, want_log: bool = False):
+        """InteriorPoint<f32>::solve on a slack-form problem (src/float.rs:42-43; lpipm_solve_f32): every operation in f32.
+        -> (status, x_slack float32 | None, fun, iterations, log rows).  The context's uploaded fp64 problem, if any, is untouched."""
+        A = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+        c = np.ascontiguousarray(c, dtype=np.float32)
+        if A.ndim != 2 or b.shape != (A.shape[0],) or c.shape != (A.shape[1],):
+            raise IncompatibleInputDimensions()
+        opts = opts or InteriorPoint.default().opts()
+        m, n = A.shape
+        x = np.full(n, np.nan, dtype=np.float32)
+        fun, it = C.c_float(np.nan), C.c_uint64(0)
+        nlog = int(opts.max_iter) if want_log else 0
+        log = (C.c_float * (7 * max(nlog, 1)))() if want_log else None
+        fp = lambda a_: a_.ctypes.data_as(C.POINTER(C.c_float))
+        rc = _capi.lib().lpipm_solve_f32(self._h, m, n, fp(A), n, fp(b), fp(c), C.c_float(c0), C.byref(opts), fp(x), C.byref(fun),
+                                         C.byref(it), C.cast(log, C.c_void_p) if want_log else None)
+        rows = [tuple(float(log[7 * i + k]) for k in range(7)) for i in range(min(int(it.value), nlog))] if want_log else []
+        has_x = rc in (_capi.OK, _capi.ITERATION_LIMIT)
+        return rc, (x if has_x else None), float(fun.value), int(it.value), rows
+
+    def k_generic_solve_f64(self, A, b, c, c0: float = 0.0, opts: "_capi.Opts | None" = None, want_log: bool = False):
+        """Test hook: the generic (scalar-type-templated) kernels of the f32 instantiation, instantiated for double."""
+        A, b, c = _f64(A), _f64(b), _f64(c)
+        opts = opts or InteriorPoint.default().opts()
+        m, n = A.shape
+        x = np.full(n, np.nan)
+        fun, it = C.c_double(np.nan), C.c_uint64(0)
+        nlog = int(opts.max_iter) if want_log else 0
+        log = (_capi.IterRow * max(nlog, 1))() if want_log else None
+        rc = _capi.lib().lpipm_k_generic_solve_f64(self._h, m, n, _p(A), n, _p(b), _p(c), C.c_double(c0), C.byref(opts), _p(x),
+                                                   C.byref(fun), C.byref(it), C.cast(log, C.c_void_p) if want_log else None)
+        rows = [(r.alpha, r.rho_p, r.rho_d, r.rho_A, r.rho_g, r.rho_mu, r.obj) for r in list(log)[:min(int(it.value), nlog)]] if want_log else []
+        return rc, x, fun.value, int(it.value), rows
+
     def set_profiling(self, on):
         """False/0 off, True/1 every phase, 2 only the A.D.A^T launches (2 events per iteration)."""
         _capi.lib().lpipm_set_profiling(self._h, int(on))
@@ -554,6 +598,12 @@ class InteriorPoint(Solver):
 
     def solve(self, problem: Problem) -> OptimizeResult:     # mod.rs:161-168
         ctx = default_context(self.device)
+        if problem.dtype == np.float32:                      # InteriorPoint<f32> (src/float.rs:42-43)
+            rc, x_slack, fun, it, _ = ctx.solve_f32(problem.A(), problem.b(), problem.c(), problem.c0(), self.opts())
+            if rc == _capi.ITERATION_LIMIT:
+                raise IterationLimitExceeded(x_slack)
+            _raise_for(rc)
+            return OptimizeResult(problem.denormalize_x_into(x_slack), fun, it)
         ctx.upload(problem)
         return self.solve_uploaded(ctx, problem)
 

@@ -71,6 +71,10 @@ SYMBOLS = {
                                     C.POINTER(C.c_int32)]),
     "lpipm_k_gemv_dual": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "lpipm_k_mfma_f64_probe": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "lpipm_solve_f32": (C.c_int, [_vp, _u64, _u64, C.POINTER(C.c_float), _u64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                                  C.POINTER(Opts), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_void_p]),
+    "lpipm_k_generic_solve_f64": (C.c_int, [_vp, _u64, _u64, _dp, _u64, _dp, _dp, C.c_double, C.POINTER(Opts), _dp, _dp,
+                                            C.POINTER(C.c_uint64), C.c_void_p]),
     "lpipm_synth_planted_lp": (C.c_int, [_u64, _u64, _u64, _dp, _dp, _dp, _dp]),
 }
 

@@ -8,6 +8,8 @@
 #include <utility>
 #include "../../include/lpipm.h"
 
+struct lpipm_ctx;
+
 namespace lpipm {
 
 // ---------------------------------------------------------------- geometry
@@ -23,6 +25,10 @@ inline uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 // LPIPM_EXPERIMENTAL=1 is set as well: a stray variable in a production (or parity-test) environment cannot change what the
 // library computes.  tests/conftest.py refuses to run with LPIPM_EXPERIMENTAL set; tests that exercise a knob set both.
 const char* lp_knob(const char* name);
+
+// ---------------------------------------------------------------- what another translation unit may know of a context
+struct lpipm_ctx_device { int device; hipStream_t stream; };
+lpipm_ctx_device lpipm_ctx_device_of(lpipm_ctx* ctx);      // solver.hip
 
 // ---------------------------------------------------------------- error plumbing
 void set_error_detail(const char* what, hipError_t e, const char* file, int line);

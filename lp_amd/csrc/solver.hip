@@ -148,6 +148,7 @@ struct lpipm_ctx {
 };
 
 static void destroy_views(lpipm_ctx* c);      // half-batch views of a lockstep batch (solve_lockstep)
+namespace lpipm { lpipm_ctx_device lpipm_ctx_device_of(lpipm_ctx* c) { return lpipm_ctx_device{c->device, c->st}; } }
 
 // The factorisation beside A.D.A^T (enqueue_factor_grouped) unless LPIPM_OVERLAP says otherwise: see lpipm_create.
 constexpr bool OVERLAP_DEFAULT = false;

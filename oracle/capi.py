@@ -175,3 +175,56 @@ def iteration(A, b, c, x, y, z, tau, kappa, ip=False, alpha0=0.99995, solver_typ
                                 _p(tk[0:1]), _p(tk[1:2]), _p(dx), _p(dy), _p(dz), _p(dtk), _p(al))
     return dict(status=rc, x=x, y=y, z=z, tau=float(tk[0]), kappa=float(tk[1]), d_x=dx, d_y=dy, d_z=dz,
                 d_tau=float(dtk[0]), d_kappa=float(dtk[1]), alpha=float(al[0]))
+
+
+# ---- the f32 instantiation of the same restatement (liboracle_ipm_f32.so: -DORACLE_F32 -fsingle-precision-constant) -------
+_LIB32_PATH = os.path.join(_HERE, "liboracle_ipm_f32.so")
+
+
+class Opts32(C.Structure):
+    _fields_ = [("tol", C.c_float), ("alpha0", C.c_float), ("max_iter", C.c_uint64),
+                ("ip", C.c_int32), ("solver_type", C.c_int32), ("disp", C.c_int32)]
+
+
+class IterRow32(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("alpha", "rho_p", "rho_d", "rho_A", "rho_g", "rho_mu", "obj")]
+
+
+_lib32 = None
+
+
+def lib32():
+    global _lib32
+    if _lib32 is None:
+        if not os.path.exists(_LIB32_PATH):
+            subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        L = C.CDLL(_LIB32_PATH)
+        fp, u64 = C.POINTER(C.c_float), C.c_uint64
+        L.oracle_default_opts.argtypes = [C.POINTER(Opts32)]
+        L.oracle_default_opts.restype = None
+        L.oracle_ipm_solve.argtypes = [u64, u64, fp, fp, fp, C.c_float, C.POINTER(Opts32), fp, fp, C.POINTER(u64),
+                                       C.POINTER(IterRow32), C.c_void_p]
+        L.oracle_ipm_solve.restype = C.c_int
+        _lib32 = L
+    return _lib32
+
+
+def solve_f32(A, b, c, c0=0.0, want_log=True, **opt_kw):
+    """The reference's algorithm with F = f32 (src/float.rs:42-43): -> dict(status, x_slack float32, fun, iterations, log)."""
+    A = np.ascontiguousarray(A, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+    c = np.ascontiguousarray(c, dtype=np.float32)
+    m, n = A.shape
+    o = Opts32()
+    lib32().oracle_default_opts(C.byref(o))
+    for k, v in opt_kw.items():
+        setattr(o, k, v)
+    x = np.full(n, np.nan, dtype=np.float32)
+    fun, it = C.c_float(np.nan), C.c_uint64(0)
+    nlog = int(min(o.max_iter, 100000)) if want_log else 0
+    log = (IterRow32 * max(nlog, 1))()
+    fp = lambda a_: a_.ctypes.data_as(C.POINTER(C.c_float))
+    rc = lib32().oracle_ipm_solve(m, n, fp(A), fp(b), fp(c), C.c_float(c0), C.byref(o), fp(x), C.byref(fun), C.byref(it),
+                                  log if want_log else None, None)
+    rows = [(r.alpha, r.rho_p, r.rho_d, r.rho_A, r.rho_g, r.rho_mu, r.obj) for r in list(log)[:min(int(it.value), nlog)]] if want_log else []
+    return dict(status=rc, x_slack=x if rc in (OK, ITERATION_LIMIT) else None, fun=float(fun.value) if rc in (OK, ITERATION_LIMIT) else None,
+                iterations=int(it.value), log=rows)

@@ -10,12 +10,19 @@
  * timing it is a faithful stand-in for `cargo run --release` of the crate (BASELINE.md 2, B-ref).
  * Compiled with -ffp-contract=off: Rust does not contract a*b+c into an fma.
  */
-#include "oracle_ipm.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+/* The f32 build of the oracle (liboracle_ipm_f32.so, Makefile): the SAME restatement with every `double` a `float`
+ * (and, by -fsingle-precision-constant, every literal too) -- what the reference's generic code is for F = f32
+ * (src/float.rs:42-43).  The switch sits behind the system headers: their prototypes must stay what libm implements
+ * (sqrt / fabs / fmax of a float argument are exact or correctly rounded after the conversion back). */
+#ifdef ORACLE_F32
+#define double float
+#endif
+#include "oracle_ipm.h"
 
 int oracle_qr_factor(uint64_t m, const double* M, double** qr_out, double** beta_out);
 int oracle_qr_solve(uint64_t m, const double* QR, const double* beta, const double* b, double* x);

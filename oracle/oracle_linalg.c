@@ -21,12 +21,21 @@
  * Any correct fp64 kernel is admissible here: the reference itself ships two interchangeable
  * backends judged at 1e-6 on x (.github/workflows/testing.yml:33,58).
  */
-#include "oracle_ipm.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+/* The f32 build of the oracle (liboracle_ipm_f32.so, Makefile): the SAME restatement with every `double` a `float`
+ * (and, by -fsingle-precision-constant, every literal too) -- what the reference's generic code is for F = f32
+ * (src/float.rs:42-43).  The switch sits behind the system headers: their prototypes must stay what libm implements
+ * (sqrt / fabs / fmax of a float argument are exact or correctly rounded after the conversion back). */
+#ifdef ORACLE_F32
+#define double float
+#endif
+#include "oracle_ipm.h"
 
+#ifndef ORACLE_F32
 typedef double v4d __attribute__((vector_size(32)));
+#endif
 
 /* ------------------------------------------------------------------ GEMM C = A(m x k) . B(k x n) */
 #define MR 6
@@ -57,6 +66,19 @@ static void pack_b(int kc, int nc, const double* B, int ldb, double* Bp) {
         }
     }
 }
+#ifdef ORACLE_F32
+/* acc[MR][NR] = Ap(MR x kc) . Bp(kc x NR): the f32 build's micro-kernel, element by element (the vector form below is laid
+ * out for 8-byte elements); the same sums in the same k order */
+static inline void micro(int kc, const double* Ap, const double* Bp, double* acc /*MR*NR*/) {
+    for (int i = 0; i < MR * NR; ++i) acc[i] = 0.0;
+    for (int p = 0; p < kc; ++p) {
+        for (int i = 0; i < MR; ++i)
+            for (int j = 0; j < NR; ++j) acc[i * NR + j] += Ap[i] * Bp[j];
+        Ap += MR;
+        Bp += NR;
+    }
+}
+#else
 /* acc[MR][NR] += Ap(MR x kc) . Bp(kc x NR) */
 static inline void micro(int kc, const double* Ap, const double* Bp, double* acc /*MR*NR*/) {
     v4d c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0}, c20 = {0}, c21 = {0};
@@ -82,6 +104,8 @@ static inline void micro(int kc, const double* Ap, const double* Bp, double* acc
     memcpy(acc + 32, &c40, 32); memcpy(acc + 36, &c41, 32);
     memcpy(acc + 40, &c50, 32); memcpy(acc + 44, &c51, 32);
 }
+
+#endif
 
 /* C(m x n, ldc) = A(m x k, lda) . B(k x n, ldb), all row-major */
 static void gemm_nn(int m, int n, int k, const double* A, int lda, const double* B, int ldb,

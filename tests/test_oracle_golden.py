@@ -117,3 +117,20 @@ def test_kernel_restatements_agree_with_numpy(built):
     w, v = rng.standard_normal(n), rng.standard_normal(m)
     assert np.abs(capi.gemv_n(A, w) - A @ w).max() < 1e-12
     assert np.abs(capi.gemv_t(A, v) - A.T @ v).max() < 1e-12
+
+
+def test_f32_build_of_the_oracle_on_the_reference_known_answers():
+    """liboracle_ipm_f32.so -- the same restatement with every `double` a `float` and every literal single precision (what
+    the reference's generic code is for F = f32, src/float.rs:42-43) -- on the reference's own known answers
+    (src/lib.rs:23-51, interior_point/mod.rs:319-344) at a tolerance f32 can reach: x to f32 accuracy.  At the default 1e-8
+    it cannot converge (f32 epsilon 6e-8) and ends in NumericalProblem: the behaviour lpipm_solve_f32 is held to."""
+    from oracle import capi
+    A = np.array([[-3.0, 1, 1, 0], [1, 2, 0, 1], [1, 1, 0, 0]])
+    r = capi.solve_f32(A, [6.0, 4, 1], [-1.0, 4, 0, 0], tol=1e-4)
+    assert r["status"] == 0 and r["x_slack"].dtype == np.float32
+    assert np.abs(r["x_slack"][:2] - np.array([1.0, 0.0])).max() < 1e-3 and abs(r["fun"] + 1.0) < 1e-3
+    Aeq = np.array([[2.0, 1, 0], [0, 2, 1], [1, 0, 2]])
+    r = capi.solve_f32(Aeq, [1.0, 2, 3], [-1.0, 4, -1.2], tol=1e-4)
+    assert r["status"] == 0 and np.abs(r["x_slack"] - np.array([1 / 3, 1 / 3, 4 / 3])).max() < 1e-3
+    r = capi.solve_f32(A, [6.0, 4, 1], [-1.0, 4, 0, 0], max_iter=200)          # default tol 1e-8
+    assert r["status"] in (capi.NUMERICAL_PROBLEM, capi.ITERATION_LIMIT)
