@@ -73,6 +73,22 @@ int main() {
             CHECK(lpipm_solve_lockstep(ctx, &o, xp.data(), fun.data(), its.data(), st.data()) == 0);
         }
     }
+    // InteriorPoint<f32> (generic kernels; upload + solve + release inside the call) and its double twin
+    {
+        LP p = make(5, 70, 150);
+        std::vector<float> Af(p.A.begin(), p.A.end()), bf(p.b.begin(), p.b.end()), cf(p.c.begin(), p.c.end()), xf(p.n);
+        lpipm_opts of = o; of.tol = 1e-3;
+        float funf; uint64_t itf;
+        std::vector<lpipm_iter_row_f32> logf(of.max_iter);
+        CHECK(lpipm_solve_f32(ctx, p.m, p.n, Af.data(), p.n, bf.data(), cf.data(), 0.0f, &of, xf.data(), &funf, &itf, logf.data()) == 0);
+        double e = 0; for (size_t i = 0; i < p.n; ++i) e = std::fmax(e, std::fabs((double)xf[i] - p.xs[i]));
+        CHECK(e < 5e-2);
+        std::vector<double> xd(p.n); double fund; uint64_t itd;
+        CHECK(lpipm_k_generic_solve_f64(ctx, p.m, p.n, p.A.data(), p.n, p.b.data(), p.c.data(), 0.0, &o, xd.data(), &fund, &itd, nullptr) == 0);
+        CHECK(maxerr(xd, p.xs) < 1e-5);
+        of.alpha0 = 2.0;
+        CHECK(lpipm_solve_f32(ctx, p.m, p.n, Af.data(), p.n, bf.data(), cf.data(), 0.0f, &of, xf.data(), &funf, &itf, nullptr) == LPIPM_INVALID_PARAMETER);
+    }
     // ub / eq upload (README LP: known answer [1, 0])
     const double c2[2] = {-1, 4}, Aub[4] = {-3, 1, 1, 2}, bub[2] = {6, 4}, Aeq[2] = {1, 1}, beq[1] = {1};
     CHECK(lpipm_upload_ub_eq(ctx, 2, 2, Aub, 2, bub, 1, Aeq, 2, beq, c2, 0.0) == 0);
