@@ -276,6 +276,50 @@ __global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
     block_reduce_store<2, false>(acc, a.red, 0);
 }
 
+// ---- the scalar steps as device functions: each is run either by its own one-wave kernel (column-split mode: a cross-rank
+// reduction sits between the vector kernel and the scalar step) or FOLDED into the vector kernel that consumes its result
+// (single GPU): every workgroup of the consumer folds the partial sums itself (fixed order: identical bits in every
+// workgroup), workgroup 0 leaves the results in S for the kernels behind it.  One dependent launch less per fold (~4.5 us)
+// for ~2 us of dependent loads in front of the consumer.  Rules that keep the folds race-free: a folded kernel never
+// reads an S entry that its own workgroup 0 writes, and never writes a reduction slot that workgroups of the SAME launch
+// still read (k_delta's minima therefore go to slots 4, 5 when folded: the dots it reads sit in 0 .. 3).
+struct DtauOut { double d_tau, d_kappa, cp, bq; };
+__device__ __forceinline__ DtauOut scalar_dtau(const VecArgs& a, int phase) {   // delta.rs:29-32, :38 (no gs: single GPU)
+    const int nblk = a.nblk;
+    double cp, cu, bq, bv;
+    if (phase == 0) { cp = fold_sum(a.red, 0, nblk); cu = fold_sum(a.red, 1, nblk); bq = fold_sum(a.red, 2, nblk); bv = fold_sum(a.red, 3, nblk); }
+    else            { cu = fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk); cp = a.S[S_CP]; bq = a.S[S_BQ]; }
+    const double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA];
+    DtauOut o;
+    o.d_tau = (S[S_RHAT_G] + 1.0 / tau * S[S_RHAT_TK] - (-cu + bv)) / (1.0 / tau * kappa + (-cp + bq));
+    o.d_kappa = 1.0 / tau * (S[S_RHAT_TK] - kappa * o.d_tau);
+    o.cp = cp; o.bq = bq;
+    return o;
+}
+// get_step_size tail (feasible_point.rs:63-71) from the folded minima in slots mslot, mslot + 1
+__device__ __forceinline__ double scalar_amin(const VecArgs& a, int mslot) {
+    const double ax = fold_min(a.red, mslot, a.nblk, 1.0), az = fold_min(a.red, mslot + 1, a.nblk, 1.0);
+    const double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA];
+    const double at = d_tau < 0.0 ? fmin(1.0, tau / -d_tau) : 1.0;
+    const double ak = d_kappa < 0.0 ? fmin(1.0, kappa / -d_kappa) : 1.0;
+    return fmin(fmin(fmin(fmin(1.0, ax), at), az), ak);
+}
+struct CorrScal { double alpha, gamma, eta, tk; };
+__device__ __forceinline__ CorrScal scalar_corr(const VecArgs& a, double amin, int ip) {   // feasible_point.rs:134-136,156-165; rhat.rs:51-74
+    const double* S = a.S;
+    const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA], mu = S[S_MU];
+    CorrScal c;
+    c.alpha = amin * 1.0;
+    if (ip) c.gamma = 10.0;
+    else c.gamma = (1.0 - c.alpha) * (1.0 - c.alpha) * fmin(0.1, 1.0 - c.alpha);
+    c.eta = ip ? 1.0 : 1.0 - c.gamma;
+    if (ip) { const double alpha_2 = c.alpha * c.alpha; c.tk = (1.0 - c.alpha) * c.gamma * mu - tau * kappa - alpha_2 * d_tau * d_kappa; }
+    else c.tk = c.gamma * mu - tau * kappa - d_tau * d_kappa;
+    return c;
+}
+
 // delta.rs:29-32 (d_tau) and :38 (d_kappa).  phase 0: predictor (all four dots fresh);
 // phase 1: corrector (c.p, b.q reused from the predictor).
 __global__ void k_scalar_dtau(VecArgs a, int phase) {
@@ -302,10 +346,19 @@ __global__ void k_scalar_dtau(VecArgs a, int phase) {
 
 // delta.rs:33-37 + the folds of get_step_size (feasible_point.rs:54-62).
 // phase 0 keeps only d_x*d_z (all the corrector needs, rhat.rs:55,64); phase 1 keeps d_x, d_y, d_z.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
     if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
-    const double d_tau = a.S[S_DTAU];
+    double d_tau;
+    if (FOLD) {     // k_scalar_dtau folded in
+        const DtauOut o = scalar_dtau(a, phase);
+        d_tau = o.d_tau;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.S[S_DTAU] = o.d_tau; a.S[S_DKAPPA] = o.d_kappa;
+            if (phase == 0) { a.S[S_CP] = o.cp; a.S[S_BQ] = o.bq; }      // (phase 1 READS them: not rewritten there)
+        }
+    } else d_tau = a.S[S_DTAU];
     double mn[2] = {1.0, 1.0};
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
         const double xj = a.x[j], zj = a.z[j];
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
     if (phase == 1)
         for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride)
             a.dy[i] = a.R[i] + a.q[i] * d_tau;
-    block_reduce_store<2, true>(mn, a.red, 0);
+    block_reduce_store<2, true>(mn, a.red, FOLD ? 4 : 0);
 }
 
 // get_step_size tail (feasible_point.rs:63-71).  phase 0: alpha of the predictor (alpha0 = 1),
@@ -359,10 +412,21 @@ __global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
 
 // Rhat::corrector vector parts (rhat.rs:51-56 / :62-64, :69-70) and the r1 / Dinv*r1 of the
 // corrector's sym_solve (newton_equations.rs:188, :220).
+template <bool FOLD>
 __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
     if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
-    const double gamma = a.S[S_GAMMA], mu = a.S[S_MU], eta = a.S[S_ETA], alpha = a.S[S_ALPHA_PRED];
+    double gamma, eta, alpha;
+    const double mu = a.S[S_MU];
+    if (FOLD) {     // k_scalar_alpha(phase 0) folded in
+        const CorrScal c = scalar_corr(a, scalar_amin(a, 4), ip);
+        gamma = c.gamma; eta = c.eta; alpha = c.alpha;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.S[S_ALPHA_PRED] = c.alpha; a.S[S_GAMMA] = c.gamma; a.S[S_ETA] = c.eta;
+            a.S[S_RHAT_G] = a.S[S_RG] * c.eta;                           // rhat.rs:71
+            a.S[S_RHAT_TK] = c.tk;
+        }
+    } else { gamma = a.S[S_GAMMA]; eta = a.S[S_ETA]; alpha = a.S[S_ALPHA_PRED]; }
     const double alpha_2 = alpha * alpha;
     const double ipterm = (1.0 - alpha) * gamma * mu;
     const double gm = gamma * mu;
@@ -380,10 +444,15 @@ __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
 }
 
 // FeasiblePoint::do_step (feasible_point.rs:76-106)
-__global__ __launch_bounds__(256) void k_step(VecArgs a, int ip) {
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_step(VecArgs a, int ip, double alpha0) {
     if (!vbatch(a, true)) return;
     const int stride = gridDim.x * 256;
-    const double alpha = a.S[S_ALPHA];
+    double alpha;
+    if (FOLD) {     // k_scalar_alpha(phase 1) folded in: the step length of the iteration (mod.rs:216-221)
+        alpha = ip ? 1.0 : scalar_amin(a, 4) * alpha0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.S[S_ALPHA] = alpha;   // (tau, kappa move in k_step_scalars, behind this launch)
+    } else alpha = a.S[S_ALPHA];
     for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
         double xn = a.x[j] + a.dx[j] * alpha;
         double zn = a.z[j] + a.dz[j] * alpha;
@@ -448,27 +517,41 @@ int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStr
     return 0;
 }
 void vec_pred_setup(const VecArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_pred_setup, vgrid(a), dim3(256), 0, st, a); }
+// Single GPU (a.gs == nullptr): the one-wave scalar kernels k_scalar_dtau / k_scalar_alpha are folded into their consumers
+// (k_delta, k_corr_setup, k_step): four dependent launches less per iteration.  Column-split mode keeps them: the cross-rank
+// reductions sit between a vector kernel and its scalar step.
+static inline bool folded(const VecArgs& a) { return a.gs == nullptr; }
 int vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_pq_uv, vgrid(a), dim3(256), 0, st, a);
+    if (folded(a)) return 0;                                          // d_tau: folded into k_delta(0)
     if (int rc = cross(a, xr, 0, 2, 0, 2, 0, 3, st)) return rc;      // c.p, c.u and the NaN-in-p flag (gs[2])
     hipLaunchKernelGGL(k_scalar_dtau, sgrid(a), dim3(64), 0, st, a, 0);
     return 0;
 }
 int vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr) {
     hipLaunchKernelGGL(k_uv_corr, vgrid(a), dim3(256), 0, st, a);
+    if (folded(a)) return 0;                                          // d_tau: folded into k_delta(1)
     if (int rc = cross(a, xr, 0, 1, 0, -1, 0, 1, st)) return rc;     // c.u
     hipLaunchKernelGGL(k_scalar_dtau, sgrid(a), dim3(64), 0, st, a, 1);
     return 0;
 }
 int vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr) {
-    hipLaunchKernelGGL(k_delta, vgrid(a), dim3(256), 0, st, a, phase);
+    if (folded(a)) {                                                  // alpha: folded into k_corr_setup (phase 0) / k_step (phase 1)
+        hipLaunchKernelGGL(k_delta<true>, vgrid(a), dim3(256), 0, st, a, phase);
+        return 0;
+    }
+    hipLaunchKernelGGL(k_delta<false>, vgrid(a), dim3(256), 0, st, a, phase);
     if (int rc = cross(a, xr, 0, 2, 1, -1, 0, 2, st)) return rc;     // ratio-test minima over x and z
     hipLaunchKernelGGL(k_scalar_alpha, sgrid(a), dim3(64), 0, st, a, phase, ip, alpha0);
     return 0;
 }
-void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) { hipLaunchKernelGGL(k_corr_setup, vgrid(a), dim3(256), 0, st, a, ip); }
-void vec_step(const VecArgs& a, int ip, hipStream_t st) {
-    hipLaunchKernelGGL(k_step, vgrid(a), dim3(256), 0, st, a, ip);
+void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) {
+    if (folded(a)) hipLaunchKernelGGL(k_corr_setup<true>, vgrid(a), dim3(256), 0, st, a, ip);
+    else           hipLaunchKernelGGL(k_corr_setup<false>, vgrid(a), dim3(256), 0, st, a, ip);
+}
+void vec_step(const VecArgs& a, int ip, double alpha0, hipStream_t st) {
+    if (folded(a)) hipLaunchKernelGGL(k_step<true>, vgrid(a), dim3(256), 0, st, a, ip, alpha0);
+    else           hipLaunchKernelGGL(k_step<false>, vgrid(a), dim3(256), 0, st, a, ip, alpha0);
     hipLaunchKernelGGL(k_step_scalars, sgrid(a), dim3(64), 0, st, a, ip);
 }
 int vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr) {

@@ -1069,7 +1069,7 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_GEMV);
     LP_TRY(vec_uv_corr(v, st, xr));
     LP_TRY(vec_delta(v, 1, ip, o->alpha0, st, xr));     // mod.rs:216-221
-    vec_step(v, ip, st);                    // feasible_point.rs:76-106
+    vec_step(v, ip, o->alpha0, st);         // feasible_point.rs:76-106 (+ the step length, mod.rs:216-221, when folded)
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
     LP_TRY(copy_status(c));
