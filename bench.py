@@ -293,8 +293,8 @@ def measure_single(m, n, steps, warmup, c2, want_cpu_baseline, rank, local_rank,
                     "note": "at this size a pass moves 4 MiB: its duration is the dependent-dispatch latency of a kernel, "
                             "not bytes (DESIGN.md 3.4)"}
     else:
-        roofline = {"kernel": "gemm_nt_streamk_w8_kernel<true> + fix-up (A.diag(x/z).A^T, lower 128x128 tiles, "
-                              "v_mfma_f64_16x16x4_f64)",
+        roofline = {"kernel": "gemm_nt_units_kernel<false> (A.diag(x/z).A^T as (tile, chunk) units with the in-launch combine, "
+                              "lower 128x128 tiles, blocks above the diagonal left out, v_mfma_f64_16x16x4_f64)",
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",

@@ -261,13 +261,41 @@ __device__ __forceinline__ d2 buf_load_d2_aux(__amdgpu_buffer_rsrc_t r, unsigned
     return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
 }
 
+// Diagonal tiles of a symmetric product (A.D.A^T): wave (wr, wc) of the 2 x 4 layout owns the 16x16 blocks with block row
+// 4 wr + mi and block column 2 wc + nj of the tile; a block is strictly above the diagonal when its column index exceeds
+// its row index, i.e. d + nj > mi with d = 2 wc - 4 wr.  Patterns: 0 nothing skipped (d <= -2), 1 (d = 0), 2 (d = 2),
+// 3 everything (d >= 4).  28 of a diagonal tile's 64 blocks go: 3 % of the MFMA work at 4096x8192, 11 % at 1024x2048.
+__device__ __forceinline__ int diag_pattern(int wr, int wc) {
+    const int d = 2 * wc - 4 * wr;
+    return d < 0 ? 0 : (d == 0 ? 1 : (d == 2 ? 2 : 3));
+}
+// Which 64 x 32 part of the tile wave w takes.  Waves w and w + 4 share a SIMD (a 512-thread workgroup's waves go round the
+// four SIMDs), and a workgroup advances at the pace of its busiest SIMD (one barrier per k-tile), so on a diagonal tile the
+// blocks left (7, 3, 0, 0 / 8, 8, 7, 3 of 8 for wc = 0..3 in rows wr = 0 / 1) are paired to 8, 8, 10, 10 per SIMD.
+__device__ __forceinline__ void wave_part(int wave, int& wr, int& wc) {
+    wr = (0x4B >> wave) & 1;             // w: 0 1 2 3 4 5 6 7 -> wr 1 1 0 1 0 0 1 0
+    wc = (0x7E84 >> (2 * wave)) & 3;     //                       wc 0 1 0 2 2 3 3 1
+}
+// the first pattern that leaves block (mi, nj) out: the block is issued while the wave's pattern is below it
+__device__ __forceinline__ constexpr int diag_group(int mi, int nj) {
+    return nj > mi ? 1 : (2 + nj > mi ? 2 : 3);
+}
+
+// f.template operator()<PAT>() for the wave-uniform pattern `pat`
+template <typename F> __device__ __forceinline__ void diag_dispatch(int pat, F&& f) {
+    if (pat == 0) f.template operator()<0>();
+    else if (pat == 1) f.template operator()<1>();
+    else if (pat == 2) f.template operator()<2>();
+    else f.template operator()<3>();
+}
+
 // One pass over the k-tiles [kb, ke) of a tile, in chunks that end at multiples of kc k-tiles (kc == 0: one chunk).
 // The software pipeline (next k-tile prefetched into registers while the current one is multiplied out of LDS) runs
 // across chunk boundaries; the hot inner loop is the plain k-tile loop and the chunk logic lives around it:
 //   touch(first)  at the start of a chunk's last k-tile: may issue loads that pull the C tile towards L2
 //   flush(first, last)  after a chunk's last k-tile: stores / adds the accumulators (the caller's business); the
 //                 accumulators restart from zero if more chunks follow.
-template <bool SCALE, typename FL, typename TC>
+template <bool SCALE, int PAT = 0, typename FL, typename TC>
 __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], double (*ldsB)[TILE][LDS_STRIDE],
                                              __amdgpu_buffer_rsrc_t Pr, unsigned p64, __amdgpu_buffer_rsrc_t Qr, unsigned q64,
                                              __amdgpu_buffer_rsrc_t Sr, unsigned offP, unsigned offQ, unsigned offS,
@@ -289,22 +317,30 @@ __device__ __forceinline__ void tile_pass_w8(double (*ldsA)[TILE][LDS_STRIDE], d
 #pragma unroll
         for (int r = 0; r < 2; ++r) *(d2*)&ldsB[buf][srow + 64 * r][lds_wcol(srow, scol)] = SCALE ? sb[r] * sv : sb[r];
     };
+    // PAT > 0: the pass of a wave over a DIAGONAL tile of a symmetric product whose blocks of groups <= PAT (diag_group) lie
+    // strictly above the diagonal and are left out -- nothing reads them.  A straight-line body per pattern: the caller
+    // switches on the wave's pattern once per pass (diag_dispatch), every other tile runs PAT = 0.
     auto mfma_ktile = [&](int cur) {
+        if constexpr (PAT < 3) {
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            d2 a[4], b[2];
-            if (round == 0) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *(const d2*)&ldsA[cur][wr * 64 + mi * 16 + fr][round * 8 + lds_rq(fr, fq)];
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) b[nj] = *(const d2*)&ldsB[cur][wc * 32 + nj * 16 + fr][round * 8 + lds_rq(fr, fq)];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int round = 0; round < 2; ++round) {
+                d2 a[4] = {}, b[2] = {};
+                if (round == 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
+                    if (diag_group(mi, 0) > PAT) a[mi] = *(const d2*)&ldsA[cur][wr * 64 + mi * 16 + fr][round * 8 + lds_rq(fr, fq)];
 #pragma unroll
-                    for (int nj = 0; nj < 2; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+                for (int nj = 0; nj < 2; ++nj)
+                    if (diag_group(3, nj) > PAT) b[nj] = *(const d2*)&ldsB[cur][wc * 32 + nj * 16 + fr][round * 8 + lds_rq(fr, fq)];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < 2; ++nj)
+                            if (diag_group(mi, nj) > PAT)
+                                acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][t], b[nj][t], acc[mi][nj], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(2);   // the short non-MFMA phase goes first: it is what the partners wait for
     };
@@ -361,7 +397,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) double ldsA[2][TILE][LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves: 64 rows x 32 columns each
+    int wr, wc;                                       // 2 x 4 waves: 64 rows x 32 columns each
+    wave_part(wave, wr, wc);
     const int fr = lane & 15, fq = lane >> 4;
     const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
     const int g = p.bk.xcd_major ? (int)blockIdx.y : xcd_remap(blockIdx.x, gridDim.x);
@@ -515,7 +552,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ __attribute__((aligned(16))) double ldsB[2][TILE][LDS_STRIDE];
     __shared__ unsigned int s_old;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;          // 2 x 4 waves: 64 rows x 32 columns each
+    int wr, wc;                                       // 2 x 4 waves: 64 rows x 32 columns each
+    wave_part(wave, wr, wc);
     const int fr = lane & 15, fq = lane >> 4;
     const int srow = tid >> 3, scol = (tid & 7) * 2;  // staging: 64 rows per pass
     const int b = p.bk.xcd_major ? (int)blockIdx.y : (int)blockIdx.x;
@@ -544,10 +582,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // chunk boundaries: nbig chunks of kc k-tiles, the rest of the contraction in pieces of ks
     auto chunk_begin = [&](int q) { const int b0 = q <= p.nbig ? q * p.kc : p.nbig * p.kc + (q - p.nbig) * p.ks; return b0 < KT ? b0 : KT; };
     const int kb = chunk_begin(q0), ke = chunk_begin(q1);
+    const int dpat = ti == tj ? diag_pattern(wr, wc) : 0;
     if (p.cpt == 1) {
         // a contraction of one chunk: the unit is the whole tile, stored directly
-        tile_pass_w8<true>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq, 0,
-                           [&](bool, bool) {}, [](bool, unsigned&, unsigned&) {});
+        diag_dispatch(dpat, [&]<int PAT>() {
+            tile_pass_w8<true, PAT>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, 0, KT, acc, srow, scol, wr, wc, fr, fq, 0,
+                                    [&](bool, bool) {}, [](bool, unsigned&, unsigned&) {});
+        });
         const unsigned rowC = (unsigned)(p.ldc * (long long)sizeof(double));
         const unsigned offC = (unsigned)(wr * 64 + fq) * rowC + (unsigned)((wc * 32 + fr) * sizeof(double));
         const __amdgpu_buffer_rsrc_t cr = make_rsrc(p.C + (long long)(ti * TILE) * p.ldc + tj * TILE, (unsigned)TILE * rowC);
@@ -569,7 +610,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else {
         int q = q0;
         const unsigned offW = (unsigned)(((wr * 64 + fq) * TILE + wc * 32 + fr) * sizeof(double));
-        tile_pass_w8<true>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq, p.kc,
+        diag_dispatch(dpat, [&]<int PAT>() {
+        tile_pass_w8<true, PAT>(ldsA, ldsB, Pr, p64, Qr, p64, Sr, offP, offP, offS, kb, ke, acc, srow, scol, wr, wc, fr, fq, p.kc,
                            [&](bool, bool) {
                                const unsigned sb = (unsigned)q * SLAB_BYTES;
 #pragma unroll
@@ -583,6 +625,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                ++q;
                            },
                            [](bool, unsigned&, unsigned&) {});
+        });
         // publish: every storing wave drains its stores, then ONE lane adds this unit's chunks to the tile's counter
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -521,7 +521,11 @@ static void plan_adat(lpipm_ctx* c, int count) {
     // 0.55 GB at C3, 38 MB per member at C4) -- up to 4 GiB per LP, beyond that (m = 16384: 34 GB) the round-2 kernel
     c->cpt = adat_units_cpt(c->npa);
     c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30) &&
-               (count > 1 || c->units_env == 2 || c->st_a != nullptr || c->ntiles <= 16);   // (tiny single LPs: one launch less, 0.042 vs 0.045 ms at 512x1024)
+               (count > 1 || c->units_env == 2 || c->st_a != nullptr || c->cpt == 1 || c->ntiles * c->cpt >= 256);
+    // (a single LP with few tiles AND several chunks -- 1000x5000: 36 tiles x 3 -- keeps the round-2 kernel: one workgroup per
+    //  tile adding the slabs at the end of a launch that never filled the chip costs more than the 16-way fix-up launch,
+    //  0.196 vs 0.151 ms; everywhere else the units kernel is level or ahead -- 4096x8192 2.206 vs 2.22 ms inside a solve,
+    //  2048x16384 1.30 vs 1.60 -- carries no spill and leaves out the blocks above the diagonal of the diagonal tiles)
     // one LP split by columns over ranks: the units kernel signals M's column groups one by one, and each group's cross-rank
     // sum runs behind the rest of the launch (enqueue_head); its slabs may take up to 32 GiB there (C5: 17 GB per rank)
     if (count == 1 && c->world > 1 && c->units_env != 0 && nt <= 64 * POTRF_OUTER &&

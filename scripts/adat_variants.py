@@ -20,7 +20,7 @@ def adat(m, n, reps=10):
     A, b, c, _ = synth.planted_lp(0, m, n)
     d = np.random.default_rng(1).uniform(0.1, 3.0, n)
     out = {}
-    for name, env in (("units", {}), ("round2", {"LPIPM_ADAT_UNITS": 0})):
+    for name, env in (("units", {"LPIPM_ADAT_UNITS": 2}), ("round2", {"LPIPM_ADAT_UNITS": 0})):
         cx = ctx_with(LPIPM_OVERLAP=0, **env)
         cx.upload_arrays(A, b, c)
         cx.k_adat(d, 2)
@@ -73,7 +73,7 @@ def lockstep(K, m, n, reps, **env):
 
 what = sys.argv[1:] or ["adat", "c3", "c4", "c2"]
 if "adat" in what:
-    for (m, n) in ((512, 1024), (1024, 2048), (2048, 4096), (4096, 8192), (1000, 5000)):
+    for (m, n) in ((512, 1024), (1024, 2048), (2048, 4096), (4096, 8192), (1000, 5000), (3000, 3500), (2048, 16384), (6144, 12288)):
         adat(m, n)
 if "c3" in what:
     x0 = solve(4096, 8192, 5, LPIPM_OVERLAP=0, LPIPM_ADAT_UNITS=0)

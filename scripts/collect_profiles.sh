@@ -25,7 +25,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   echo "pmc pass $tag done"
 done
 cd $REPO
-python3 scripts/pmc_summary.py gemm_nt_streamk_w8 4096 8192 $OUT/${R}_adat_pmc.json /tmp/p_pmc_c3 > /dev/null
+PMC_LPS_PER_LAUNCH=1 python3 scripts/pmc_summary.py gemm_nt_units 4096 8192 $OUT/${R}_adat_pmc.json /tmp/p_pmc_c3 > /dev/null
 python3 scripts/pmc_summary.py gemv_dual 512 1024 $OUT/${R}_gemv_pmc.json /tmp/p_pmc_c2 > /dev/null
 python3 scripts/pmc_summary.py gemm_nt_units 1024 2048 $OUT/${R}_adat_c4_pmc.json /tmp/p_pmc_c4 > /dev/null
 python3 bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
