@@ -725,13 +725,15 @@ hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, i
     const int nb = mp / NB;
     // Look-ahead (one LP, enough trailing matrix for it to matter): behind outer panel p the block columns of panel p+1 are
     // updated on the chain stream and the chain goes on; the rest of the update runs on the side stream beside it and has to
-    // be complete only before panel p+1's own trailing update touches the same columns.  OPT-IN (LPIPM_LOOKAHEAD=1): measured
-    // at m = 4096 1910 -> 1855 us with 8 CUs per XCC kept free for the chain, 1870 with 4, 1890 with 2, 1905 with a
-    // low-priority unmasked side stream; at m = 2048 750 -> 775 whatever the setting.  Trace: the chain's part of the update is
+    // be complete only before panel p+1's own trailing update touches the same columns.  On from m = 4096 (round 3; round 2
+    // had it opt-in): measured at m = 4096 1910 -> 1855 us (round 2), 1866 -> 1820 us and 209.5 -> 214.2 it/s at C3 (round 3,
+    // same box, alternating runs) with 8 CUs per XCC kept free for the chain, 1870 with 4, 1890 with 2, 1905 with a
+    // low-priority unmasked side stream; at m = 2048 750 -> 775 whatever the setting, hence the threshold (LPIPM_LOOKAHEAD=1
+    // lowers it to 12 blocks, =0 switches the side stream off).  Trace: the chain's part of the update is
     // one round of K = 512 tiles (45 us where the whole update takes 105), and the chain's next panel solve and inner update
     // take 2-4x as long beside the side stream's workgroups (26 and 46 us instead of 10): 270 us per outer panel against 275.
     const int npanel = (nb + OUTER - 1) / OUTER;
-    const bool ahead = la && la->side && bt.count == 1 && (int)la->ev_chain.size() >= npanel && nb >= 3 * OUTER;
+    const bool ahead = la && la->side && bt.count == 1 && (int)la->ev_chain.size() >= npanel && nb >= 3 * OUTER && nb >= la->min_nb;
     int pending = -1;                            // panel whose rest-update the chain stream has not waited for yet
     for (int J0 = 0, pnl = 0; J0 < nb; J0 += OUTER, ++pnl) {
         const int J1 = J0 + OUTER < nb ? J0 + OUTER : nb;

@@ -213,6 +213,7 @@ void factor_plan_destroy(FactorPlan& plan);
 struct PotrfLookahead {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_chain, ev_rest;
+    int min_nb = 32;         // 128-blocks from which the look-ahead is used (default: m >= 4096; LPIPM_LOOKAHEAD=1: 12)
 };
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
                         const Batch& bt = Batch{}, const PotrfLookahead* la = nullptr);

@@ -354,15 +354,16 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
             }
         }
     }
-    // Side stream for the look-ahead of the factorisation's trailing updates (launch_potrf): OPT-IN, LPIPM_LOOKAHEAD=1 (see
-    // there for the measurements).  CU-masked (bit i = CU i/8 of XCC i%8): the first R CUs of every XCC stay free for the chain
+    // Side stream for the look-ahead of the factorisation's trailing updates (launch_potrf; used from m = 4096, see there for
+    // the measurements; LPIPM_LOOKAHEAD=0 switches it off, =1 lowers the threshold to m = 1536).  CU-masked (bit i = CU i/8 of XCC i%8): the first R CUs of every XCC stay free for the chain
     // stream's kernels -- the diagonal-block kernel needs a CU to itself (150 KB of LDS) and would otherwise wait for a
     // side-stream tile to drain.  LPIPM_LOOKAHEAD_CUS=R sets R (default 8; 0: an unmasked low-priority stream).
     {
         const char* on = lp_knob("LPIPM_LOOKAHEAD");
         int R = 8;
         if (const char* e = lp_knob("LPIPM_LOOKAHEAD_CUS")) { const int v = atoi(e); if (v >= 0 && v <= 16) R = v; }
-        if (on && on[0] == '1' && c->num_cu == 256) {
+        if (on && on[0] == '1') c->la.min_nb = 3 * POTRF_OUTER;
+        if (!(on && on[0] == '0') && c->num_cu == 256) {
             uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < 256; ++i) if ((i / 8) >= R) mk[i / 32] |= 1u << (i % 32);
             int lo = 0, hi = 0;

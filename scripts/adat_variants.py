@@ -85,6 +85,8 @@ if "c4" in what:
     a = lockstep(32, 1024, 2048, 5, LPIPM_ADAT_UNITS=0)
     b = lockstep(32, 1024, 2048, 5)
     print("c4: units bit-identical to round2:", np.array_equal(a, b), flush=True)
+if "c4only" in what:
+    lockstep(32, 1024, 2048, 5)
 if "c2" in what:
     solve(512, 1024, 50, LPIPM_OVERLAP=0, LPIPM_ADAT_UNITS=0)
     solve(512, 1024, 50, LPIPM_OVERLAP=0)

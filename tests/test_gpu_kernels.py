@@ -99,20 +99,26 @@ def test_potrf_is_bitwise_reproducible(ctx):
         assert info == 0 and np.array_equal(np.tril(L), np.tril(L0)) and np.array_equal(V, V0)
 
 
-def test_potrf_lookahead_is_bit_identical(built, monkeypatch):
-    """LPIPM_LOOKAHEAD=1 (trailing updates split: the next outer panel's columns on the chain stream, the rest on a CU-masked
-    side stream behind events; opt-in) must give the factor of the serial schedule bit for bit: every element is
-    the same k-ordered sum whatever the tile shapes and the streams."""
+@pytest.mark.parametrize("m,force", [(2048, True), (4096, False)])
+def test_potrf_lookahead_is_bit_identical(built, monkeypatch, m, force):
+    """The look-ahead of the factorisation (trailing updates split: the next outer panel's columns on the chain stream, the rest
+    on a CU-masked side stream behind events; default from m = 4096, LPIPM_LOOKAHEAD=1 forces it from m = 1536)
+    must give the factor of the serial schedule (LPIPM_LOOKAHEAD=0) bit for bit: every element is the same k-ordered sum
+    whatever the tile shapes and the streams."""
     import lp_amd
-    m = 2048
     rng = np.random.default_rng(11)
     B = rng.standard_normal((m, m + 9))
     M = B @ B.T
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
+    monkeypatch.setenv("LPIPM_LOOKAHEAD", "0")
     serial = lp_amd.Context(0)
     L0, info0, _ = serial.k_potrf(M)
     serial.close()
-    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
-    monkeypatch.setenv("LPIPM_LOOKAHEAD", "1")
+    if force:
+        monkeypatch.setenv("LPIPM_LOOKAHEAD", "1")
+    else:
+        monkeypatch.delenv("LPIPM_LOOKAHEAD")
+        monkeypatch.delenv("LPIPM_EXPERIMENTAL")
     ahead = lp_amd.Context(0)
     for _ in range(3):
         L1, info1, _ = ahead.k_potrf(M)
