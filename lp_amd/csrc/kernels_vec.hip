@@ -122,12 +122,16 @@ __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
 //   r_P = b*tau - A.x            (Ax from gemv_n)
 //   r_D = c*tau - A^T.y - z      (A^T.y = sum of the gemv_t row-split slabs)
 // partial sums: |r_P|^2, b.y, |r_D|^2, c.x, x.z, c.(x/tau)   (indicators.rs:41-44)
-__global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
-    if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
+// A vector kernel's work is written once, for the thread `vt` of the (virtual) 256-thread block `vb` of `nvb`: the plain
+// kernels pass (blockIdx.x, threadIdx.x, gridDim.x); the fused single-workgroup kernels further down walk the same
+// virtual blocks four at a time and rebuild the same reduction tree, so their sums have the same bits.
+struct VThread { int vb, vt, nvb; };
+__device__ __forceinline__ VThread plain_thread() { return VThread{(int)blockIdx.x, (int)threadIdx.x, (int)gridDim.x}; }
+
+__device__ __forceinline__ void body_residuals(const VecArgs& a, const VThread t, double (&acc)[6]) {
+    const int stride = t.nvb * 256;
     const double tau = a.S[S_TAU];
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) {
+    for (int i = t.vb * 256 + t.vt; i < a.m; i += stride) {
         double ax = a.Ax[i];
         for (int ch = 1; ch < a.ax_chunks; ++ch) ax += a.Ax[(long long)ch * a.mp + i];
         const double r = a.b[i] * tau - ax;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
         acc[0] += r * r;
         acc[1] += a.b[i] * a.y[i];
     }
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
         double aty = 0.0;
         for (int s = 0; s < a.nsplit; ++s) aty += a.ATpart[(long long)s * a.np + j];
         const double xj = a.x[j], zj = a.z[j], cj = a.c[j];
@@ -146,20 +150,19 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
         acc[4] += xj * zj;
         acc[5] += cj * (xj / tau);
     }
+}
+__global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
+    if (!vbatch(a, true)) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    body_residuals(a, plain_thread(), acc);
     block_reduce_store<6, false>(acc, a.red, 0);
 }
 
 // Residuals::calculate + Indicators::from_point_and_problem + Indicators::status
 // (residual.rs:33-43, indicators.rs:37-55, :57-83), then the scalars the NEXT get_delta starts
 // from (feasible_point.rs:119-125, rhat.rs:31,33).
-__global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol) {
-    if (!vbatch(a, true)) return;
-    const int nblk = a.nblk;
-    // |r_P|^2 and b.y run over m (replicated on every rank); the other four over the (possibly split) n
-    const double rp2 = fold_sum(a.red, 0, nblk), by = fold_sum(a.red, 1, nblk);
-    const double rd2 = a.gs ? a.gs[2] : fold_sum(a.red, 2, nblk), cx = a.gs ? a.gs[3] : fold_sum(a.red, 3, nblk);
-    const double xz = a.gs ? a.gs[4] : fold_sum(a.red, 4, nblk), cxt = a.gs ? a.gs[5] : fold_sum(a.red, 5, nblk);
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void scalar_indicators(const VecArgs& a, int is_init, int ip_next, double tol, double rp2, double by,
+                                                  double rd2, double cx, double xz, double cxt) {    // ONE thread
     double* S = a.S;
     const double tau = S[S_TAU], kappa = S[S_KAPPA];
     const double rho_p = sqrt(rp2);                                   // residual.rs:34
@@ -204,6 +207,16 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
     S[S_RHAT_G] = rG * eta;                                           // rhat.rs:31
     S[S_RHAT_TK] = gamma * mu - tau * kappa;                          // rhat.rs:33
 }
+__global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol) {
+    if (!vbatch(a, true)) return;
+    const int nblk = a.nblk;
+    // |r_P|^2 and b.y run over m (replicated on every rank); the other four over the (possibly split) n
+    const double rp2 = fold_sum(a.red, 0, nblk), by = fold_sum(a.red, 1, nblk);
+    const double rd2 = a.gs ? a.gs[2] : fold_sum(a.red, 2, nblk), cx = a.gs ? a.gs[3] : fold_sum(a.red, 3, nblk);
+    const double xz = a.gs ? a.gs[4] : fold_sum(a.red, 4, nblk), cxt = a.gs ? a.gs[5] : fold_sum(a.red, 5, nblk);
+    if (threadIdx.x != 0) return;
+    scalar_indicators(a, is_init, ip_next, tol, rp2, by, rd2, cx, xz, cxt);
+}
 
 // ---------------------------------------------------------------- predictor set-up
 // newton_equations.rs:54 (Dinv = x/z); rhat.rs:29-32 (predictor r_hat); the r1 argument of the
@@ -228,12 +241,10 @@ __global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
 
 // sym_solve epilogue u = Dinv*(A^T.v - r1) for both solves of the predictor
 // (newton_equations.rs:223), the four dots of delta.rs:29-32 and the NaN check of :190-194.
-__global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
-    if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
-    double acc[4] = {0, 0, 0, 0};
+__device__ __forceinline__ int body_pq_uv(const VecArgs& a, const VThread t, double (&acc)[4]) {
+    const int stride = t.nvb * 256;
     int nan = 0;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
         double atq = 0.0, atv = 0.0;
         for (int s = 0; s < a.nsplit; ++s) {
             atq += a.ATpart[((long long)s * 2 + 0) * a.np + j];
@@ -248,31 +259,39 @@ __global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
         acc[1] += cj * u;
         nan |= (p != p);
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) {
+    for (int i = t.vb * 256 + t.vt; i < a.m; i += stride) {
         const double q = a.R[i], v = a.R[a.mp + i], bi = a.b[i];
         a.q[i] = q;
         acc[2] += bi * q;
         acc[3] += bi * v;
         nan |= (q != q);
     }
-    if (nan) atomicOr(a.flags, FLAG_NAN_PQ);
+    return nan;
+}
+__global__ __launch_bounds__(256) void k_pq_uv(VecArgs a) {
+    if (!vbatch(a, true)) return;
+    double acc[4] = {0, 0, 0, 0};
+    if (body_pq_uv(a, plain_thread(), acc)) atomicOr(a.flags, FLAG_NAN_PQ);
     block_reduce_store<4, false>(acc, a.red, 0);
 }
 
 // corrector: only (u, v) change; (p, q) are identical to the predictor's (the reference recomputes
 // them, feasible_point.rs:149 -> newton_equations.rs:187, with the same inputs and factor).
-__global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
-    if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
-    double acc[2] = {0, 0};
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+__device__ __forceinline__ void body_uv_corr(const VecArgs& a, const VThread t, double (&acc)[2]) {
+    const int stride = t.nvb * 256;
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
         double atv = 0.0;
         for (int s = 0; s < a.nsplit; ++s) atv += a.ATpart[(long long)s * a.np + j];
         const double u = a.dinv[j] * (atv - a.r1[j]);
         a.u[j] = u;
         acc[0] += a.c[j] * u;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) acc[1] += a.b[i] * a.R[i];
+    for (int i = t.vb * 256 + t.vt; i < a.m; i += stride) acc[1] += a.b[i] * a.R[i];
+}
+__global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
+    if (!vbatch(a, true)) return;
+    double acc[2] = {0, 0};
+    body_uv_corr(a, plain_thread(), acc);
     block_reduce_store<2, false>(acc, a.red, 0);
 }
 
@@ -284,11 +303,7 @@ __global__ __launch_bounds__(256) void k_uv_corr(VecArgs a) {
 // reads an S entry that its own workgroup 0 writes, and never writes a reduction slot that workgroups of the SAME launch
 // still read (k_delta's minima therefore go to slots 4, 5 when folded: the dots it reads sit in 0 .. 3).
 struct DtauOut { double d_tau, d_kappa, cp, bq; };
-__device__ __forceinline__ DtauOut scalar_dtau(const VecArgs& a, int phase) {   // delta.rs:29-32, :38 (no gs: single GPU)
-    const int nblk = a.nblk;
-    double cp, cu, bq, bv;
-    if (phase == 0) { cp = fold_sum(a.red, 0, nblk); cu = fold_sum(a.red, 1, nblk); bq = fold_sum(a.red, 2, nblk); bv = fold_sum(a.red, 3, nblk); }
-    else            { cu = fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk); cp = a.S[S_CP]; bq = a.S[S_BQ]; }
+__device__ __forceinline__ DtauOut dtau_from(const VecArgs& a, double cp, double cu, double bq, double bv) {   // delta.rs:29-32, :38
     const double* S = a.S;
     const double tau = S[S_TAU], kappa = S[S_KAPPA];
     DtauOut o;
@@ -297,19 +312,29 @@ __device__ __forceinline__ DtauOut scalar_dtau(const VecArgs& a, int phase) {   
     o.cp = cp; o.bq = bq;
     return o;
 }
-// get_step_size tail (feasible_point.rs:63-71) from the folded minima in slots mslot, mslot + 1
-__device__ __forceinline__ double scalar_amin(const VecArgs& a, int mslot) {
-    const double ax = fold_min(a.red, mslot, a.nblk, 1.0), az = fold_min(a.red, mslot + 1, a.nblk, 1.0);
+__device__ __forceinline__ DtauOut scalar_dtau(const VecArgs& a, int phase) {   // (no gs: single GPU)
+    const int nblk = a.nblk;
+    double cp, cu, bq, bv;
+    if (phase == 0) { cp = fold_sum(a.red, 0, nblk); cu = fold_sum(a.red, 1, nblk); bq = fold_sum(a.red, 2, nblk); bv = fold_sum(a.red, 3, nblk); }
+    else            { cu = fold_sum(a.red, 0, nblk); bv = fold_sum(a.red, 1, nblk); cp = a.S[S_CP]; bq = a.S[S_BQ]; }
+    return dtau_from(a, cp, cu, bq, bv);
+}
+// get_step_size tail (feasible_point.rs:63-71) from the minima over x and z
+__device__ __forceinline__ double amin_from(const VecArgs& a, double ax, double az, double d_tau, double d_kappa) {
     const double* S = a.S;
-    const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA];
+    const double tau = S[S_TAU], kappa = S[S_KAPPA];
     const double at = d_tau < 0.0 ? fmin(1.0, tau / -d_tau) : 1.0;
     const double ak = d_kappa < 0.0 ? fmin(1.0, kappa / -d_kappa) : 1.0;
     return fmin(fmin(fmin(fmin(1.0, ax), at), az), ak);
 }
+__device__ __forceinline__ double scalar_amin(const VecArgs& a, int mslot) {     // from the folded minima in slots mslot, mslot + 1
+    const double ax = fold_min(a.red, mslot, a.nblk, 1.0), az = fold_min(a.red, mslot + 1, a.nblk, 1.0);
+    return amin_from(a, ax, az, a.S[S_DTAU], a.S[S_DKAPPA]);
+}
 struct CorrScal { double alpha, gamma, eta, tk; };
-__device__ __forceinline__ CorrScal scalar_corr(const VecArgs& a, double amin, int ip) {   // feasible_point.rs:134-136,156-165; rhat.rs:51-74
+__device__ __forceinline__ CorrScal corr_from(const VecArgs& a, double amin, int ip, double d_tau, double d_kappa) {   // feasible_point.rs:134-136,156-165; rhat.rs:51-74
     const double* S = a.S;
-    const double tau = S[S_TAU], kappa = S[S_KAPPA], d_tau = S[S_DTAU], d_kappa = S[S_DKAPPA], mu = S[S_MU];
+    const double tau = S[S_TAU], kappa = S[S_KAPPA], mu = S[S_MU];
     CorrScal c;
     c.alpha = amin * 1.0;
     if (ip) c.gamma = 10.0;
@@ -318,6 +343,9 @@ __device__ __forceinline__ CorrScal scalar_corr(const VecArgs& a, double amin, i
     if (ip) { const double alpha_2 = c.alpha * c.alpha; c.tk = (1.0 - c.alpha) * c.gamma * mu - tau * kappa - alpha_2 * d_tau * d_kappa; }
     else c.tk = c.gamma * mu - tau * kappa - d_tau * d_kappa;
     return c;
+}
+__device__ __forceinline__ CorrScal scalar_corr(const VecArgs& a, double amin, int ip) {
+    return corr_from(a, amin, ip, a.S[S_DTAU], a.S[S_DKAPPA]);
 }
 
 // delta.rs:29-32 (d_tau) and :38 (d_kappa).  phase 0: predictor (all four dots fresh);
@@ -346,10 +374,24 @@ __global__ void k_scalar_dtau(VecArgs a, int phase) {
 
 // delta.rs:33-37 + the folds of get_step_size (feasible_point.rs:54-62).
 // phase 0 keeps only d_x*d_z (all the corrector needs, rhat.rs:55,64); phase 1 keeps d_x, d_y, d_z.
+__device__ __forceinline__ void body_delta(const VecArgs& a, const VThread t, int phase, double d_tau, double (&mn)[2]) {
+    const int stride = t.nvb * 256;
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
+        const double xj = a.x[j], zj = a.z[j];
+        const double dx = a.u[j] + a.p[j] * d_tau;
+        const double dz = (a.xs[j] - zj * dx) / xj;
+        if (dx < 0.0) mn[0] = fmin(mn[0], xj / -dx);
+        if (dz < 0.0) mn[1] = fmin(mn[1], zj / -dz);
+        if (phase == 0) a.dxdz[j] = dx * dz;
+        else { a.dx[j] = dx; a.dz[j] = dz; }
+    }
+    if (phase == 1)
+        for (int i = t.vb * 256 + t.vt; i < a.m; i += stride)
+            a.dy[i] = a.R[i] + a.q[i] * d_tau;
+}
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
     if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
     double d_tau;
     if (FOLD) {     // k_scalar_dtau folded in
         const DtauOut o = scalar_dtau(a, phase);
@@ -360,18 +402,7 @@ __global__ __launch_bounds__(256) void k_delta(VecArgs a, int phase) {
         }
     } else d_tau = a.S[S_DTAU];
     double mn[2] = {1.0, 1.0};
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
-        const double xj = a.x[j], zj = a.z[j];
-        const double dx = a.u[j] + a.p[j] * d_tau;
-        const double dz = (a.xs[j] - zj * dx) / xj;
-        if (dx < 0.0) mn[0] = fmin(mn[0], xj / -dx);
-        if (dz < 0.0) mn[1] = fmin(mn[1], zj / -dz);
-        if (phase == 0) a.dxdz[j] = dx * dz;
-        else { a.dx[j] = dx; a.dz[j] = dz; }
-    }
-    if (phase == 1)
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride)
-            a.dy[i] = a.R[i] + a.q[i] * d_tau;
+    body_delta(a, plain_thread(), phase, d_tau, mn);
     block_reduce_store<2, true>(mn, a.red, FOLD ? 4 : 0);
 }
 
@@ -412,10 +443,27 @@ __global__ void k_scalar_alpha(VecArgs a, int phase, int ip, double alpha0) {
 
 // Rhat::corrector vector parts (rhat.rs:51-56 / :62-64, :69-70) and the r1 / Dinv*r1 of the
 // corrector's sym_solve (newton_equations.rs:188, :220).
+__device__ __forceinline__ void body_corr_setup(const VecArgs& a, const VThread t, int ip, double gamma, double eta, double alpha,
+                                                double mu) {
+    const int stride = t.nvb * 256;
+    const double alpha_2 = alpha * alpha;
+    const double ipterm = (1.0 - alpha) * gamma * mu;
+    const double gm = gamma * mu;
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
+        const double xj = a.x[j], zj = a.z[j], pr = a.dxdz[j];
+        double xs;
+        if (ip) xs = (xj * -1.0) * zj - pr * alpha_2 + ipterm;
+        else    xs = (xj * -1.0) * zj + gm - pr;
+        const double r1 = a.rD[j] * eta - xs / xj;
+        a.xs[j] = xs;
+        a.r1[j] = r1;
+        a.W[j] = a.dinv[j] * r1;
+    }
+    for (int i = t.vb * 256 + t.vt; i < a.m; i += stride) a.rP2[i] = a.rP[i] * eta;
+}
 template <bool FOLD>
 __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
     if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
     double gamma, eta, alpha;
     const double mu = a.S[S_MU];
     if (FOLD) {     // k_scalar_alpha(phase 0) folded in
@@ -427,40 +475,30 @@ __global__ __launch_bounds__(256) void k_corr_setup(VecArgs a, int ip) {
             a.S[S_RHAT_TK] = c.tk;
         }
     } else { gamma = a.S[S_GAMMA]; eta = a.S[S_ETA]; alpha = a.S[S_ALPHA_PRED]; }
-    const double alpha_2 = alpha * alpha;
-    const double ipterm = (1.0 - alpha) * gamma * mu;
-    const double gm = gamma * mu;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
-        const double xj = a.x[j], zj = a.z[j], pr = a.dxdz[j];
-        double xs;
-        if (ip) xs = (xj * -1.0) * zj - pr * alpha_2 + ipterm;
-        else    xs = (xj * -1.0) * zj + gm - pr;
-        const double r1 = a.rD[j] * eta - xs / xj;
-        a.xs[j] = xs;
-        a.r1[j] = r1;
-        a.W[j] = a.dinv[j] * r1;
-    }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.rP2[i] = a.rP[i] * eta;
+    body_corr_setup(a, plain_thread(), ip, gamma, eta, alpha, mu);
 }
 
 // FeasiblePoint::do_step (feasible_point.rs:76-106)
-template <bool FOLD>
-__global__ __launch_bounds__(256) void k_step(VecArgs a, int ip, double alpha0) {
-    if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
-    double alpha;
-    if (FOLD) {     // k_scalar_alpha(phase 1) folded in: the step length of the iteration (mod.rs:216-221)
-        alpha = ip ? 1.0 : scalar_amin(a, 4) * alpha0;
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.S[S_ALPHA] = alpha;   // (tau, kappa move in k_step_scalars, behind this launch)
-    } else alpha = a.S[S_ALPHA];
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+__device__ __forceinline__ void body_step(const VecArgs& a, const VThread t, int ip, double alpha) {
+    const int stride = t.nvb * 256;
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
         double xn = a.x[j] + a.dx[j] * alpha;
         double zn = a.z[j] + a.dz[j] * alpha;
         if (ip) { xn = fmax(xn, 1.0); zn = fmax(zn, 1.0); }
         a.x[j] = xn;
         a.z[j] = zn;
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.m; i += stride) a.y[i] = a.y[i] + a.dy[i] * alpha;
+    for (int i = t.vb * 256 + t.vt; i < a.m; i += stride) a.y[i] = a.y[i] + a.dy[i] * alpha;
+}
+template <bool FOLD>
+__global__ __launch_bounds__(256) void k_step(VecArgs a, int ip, double alpha0) {
+    if (!vbatch(a, true)) return;
+    double alpha;
+    if (FOLD) {     // k_scalar_alpha(phase 1) folded in: the step length of the iteration (mod.rs:216-221)
+        alpha = ip ? 1.0 : scalar_amin(a, 4) * alpha0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.S[S_ALPHA] = alpha;   // (tau, kappa move in k_step_scalars, behind this launch)
+    } else alpha = a.S[S_ALPHA];
+    body_step(a, plain_thread(), ip, alpha);
 }
 // tau / kappa part of do_step: separate one-thread launch so that no kernel both reads and writes S
 __global__ void k_step_scalars(VecArgs a, int ip) {
@@ -473,6 +511,155 @@ __global__ void k_step_scalars(VecArgs a, int ip) {
     if (ip) { tau = fmax(tau, 1.0); kappa = fmax(kappa, 1.0); }
     S[S_TAU] = tau;
     S[S_KAPPA] = kappa;
+}
+
+// ---------------------------------------------------------------- fused vector stage (one workgroup per LP)
+// For SMALL LPs (FUSED_USE_NBLK virtual blocks: n, m <= 1024) the runs of vector kernels between two passes over A are ONE launch of
+// one 1024-thread workgroup per LP: the workgroup walks the virtual 256-thread blocks four at a time (a wave is one of a
+// block's four), and what separated the kernels -- a grid-wide reduction -- is a workgroup reduction with the SAME tree:
+// butterfly inside each (virtual) wave, (w0 + w1) + (w2 + w3) per block, block sums into lanes 0 .. nblk-1 of a wave
+// (0.0 + r, as fold_sum starts from zero) and the butterfly again.  Every thread handles the same elements in every phase,
+// so what a phase stores for the next one is read back by the thread that wrote it.  The iterates are bit-identical to
+// the kernel-by-kernel path (tests/test_gpu_solve.py, LPIPM_VEC_FUSED=0 as the other side).  What it saves is dependent
+// launches: 3 -> 1 behind the predictor's passes, 4 -> 1 behind the corrector's, 2 -> 1 behind the residual pass.
+constexpr int FUSED_THREADS = 1024;
+constexpr int FUSED_MAX_NBLK = 32;    // what the kernels can do
+constexpr int FUSED_USE_NBLK = 4;     // where they are used: n, m <= 1024.  One workgroup also pays every global round trip on
+                                      // its own: vector stage per iteration 0.070 -> 0.057 ms at 512x1024, but 0.102 -> 0.113
+                                      // at 32 x (1024x2048) and 0.094 -> 0.383 at 4096x8192 (32 row-split slabs of A^T.v per
+                                      // column through one CU)
+template <int K> struct FusedSm { double w[K][FUSED_MAX_NBLK][4]; double r[K][FUSED_MAX_NBLK]; };
+__device__ __forceinline__ VThread fused_thread(const VecArgs& a, int round) {
+    return VThread{4 * round + (int)(threadIdx.x >> 8), (int)(threadIdx.x & 255), a.nblk};
+}
+// the partial of this thread's (virtual) wave for each of K values -> sm.w
+template <int K, bool IS_MIN>
+__device__ __forceinline__ void fused_wave_part(const double (&v)[K], FusedSm<K>& sm, int vb) {
+    const int lane = threadIdx.x & 63, vw = (threadIdx.x >> 6) & 3;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double w = IS_MIN ? wave_min(v[k]) : wave_sum(v[k]);
+        if (lane == 0) sm.w[k][vb][vw] = w;
+    }
+}
+// all parts in: every thread gets the K totals (same tree as block_reduce_store + fold_sum / fold_min)
+template <int K, bool IS_MIN>
+__device__ __forceinline__ void fused_total(FusedSm<K>& sm, int nblk, double (&out)[K]) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * nblk; e += FUSED_THREADS) {
+        const int k = e / nblk, b = e - k * nblk;
+        const double* w = sm.w[k][b];
+        sm.r[k][b] = IS_MIN ? fmin(fmin(w[0], w[1]), fmin(w[2], w[3])) : (w[0] + w[1]) + (w[2] + w[3]);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = IS_MIN ? 1.0 : 0.0;
+        if (lane < nblk) s = IS_MIN ? fmin(s, sm.r[k][lane]) : s + sm.r[k][lane];
+        out[k] = IS_MIN ? wave_min(s) : wave_sum(s);
+    }
+    __syncthreads();        // sm may be written again
+}
+
+// k_pq_uv -> d_tau (delta.rs:29-32,38) -> k_delta(0) -> alpha, gamma, eta (feasible_point.rs:134-136) -> k_corr_setup
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_predictor(VecArgs a, int ip) {
+    if (!vbatch(a, true)) return;
+    __shared__ FusedSm<4> sm4;
+    __shared__ FusedSm<2> sm2;
+    const int rounds = (a.nblk + 3) / 4;
+    int nan = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;                      // (whole waves)
+        double acc[4] = {0, 0, 0, 0};
+        nan |= body_pq_uv(a, t, acc);
+        fused_wave_part<4, false>(acc, sm4, t.vb);
+    }
+    if (nan) atomicOr(a.flags, FLAG_NAN_PQ);
+    double dots[4];
+    fused_total<4, false>(sm4, a.nblk, dots);
+    const DtauOut o = dtau_from(a, dots[0], dots[1], dots[2], dots[3]);
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        double mn[2] = {1.0, 1.0};
+        body_delta(a, t, 0, o.d_tau, mn);
+        fused_wave_part<2, true>(mn, sm2, t.vb);
+    }
+    double mins[2];
+    fused_total<2, true>(sm2, a.nblk, mins);
+    const CorrScal c = corr_from(a, amin_from(a, mins[0], mins[1], o.d_tau, o.d_kappa), ip, o.d_tau, o.d_kappa);
+    const double mu = a.S[S_MU], rg = a.S[S_RG];
+    __syncthreads();                                       // every read of S above precedes the writes below
+    if (threadIdx.x == 0) {
+        a.S[S_DTAU] = o.d_tau; a.S[S_DKAPPA] = o.d_kappa; a.S[S_CP] = o.cp; a.S[S_BQ] = o.bq;
+        a.S[S_ALPHA_PRED] = c.alpha; a.S[S_GAMMA] = c.gamma; a.S[S_ETA] = c.eta;
+        a.S[S_RHAT_G] = rg * c.eta;                        // rhat.rs:71
+        a.S[S_RHAT_TK] = c.tk;
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        body_corr_setup(a, t, ip, c.gamma, c.eta, c.alpha, mu);
+    }
+}
+
+// k_uv_corr -> d_tau -> k_delta(1) -> the step length (mod.rs:216-221) -> do_step (feasible_point.rs:76-106) incl. tau, kappa
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_corrector(VecArgs a, int ip, double alpha0) {
+    if (!vbatch(a, true)) return;
+    __shared__ FusedSm<2> sm2;
+    const int rounds = (a.nblk + 3) / 4;
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        double acc[2] = {0, 0};
+        body_uv_corr(a, t, acc);
+        fused_wave_part<2, false>(acc, sm2, t.vb);
+    }
+    double dots[2];
+    fused_total<2, false>(sm2, a.nblk, dots);
+    const DtauOut o = dtau_from(a, a.S[S_CP], dots[0], a.S[S_BQ], dots[1]);
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        double mn[2] = {1.0, 1.0};
+        body_delta(a, t, 1, o.d_tau, mn);
+        fused_wave_part<2, true>(mn, sm2, t.vb);
+    }
+    double mins[2];
+    fused_total<2, true>(sm2, a.nblk, mins);
+    const double alpha = ip ? 1.0 : amin_from(a, mins[0], mins[1], o.d_tau, o.d_kappa) * alpha0;
+    double tau = a.S[S_TAU] + o.d_tau * alpha;             // k_step_scalars
+    double kappa = a.S[S_KAPPA] + o.d_kappa * alpha;
+    if (ip) { tau = fmax(tau, 1.0); kappa = fmax(kappa, 1.0); }
+    __syncthreads();                                       // every read of S above precedes the writes below
+    if (threadIdx.x == 0) {
+        a.S[S_DTAU] = o.d_tau; a.S[S_DKAPPA] = o.d_kappa; a.S[S_ALPHA] = alpha;
+        a.S[S_TAU] = tau; a.S[S_KAPPA] = kappa;
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        body_step(a, t, ip, alpha);
+    }
+}
+
+// k_residuals -> k_scalar_indicators
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_residuals(VecArgs a, int is_init, int ip_next, double tol) {
+    if (!vbatch(a, true)) return;
+    __shared__ FusedSm<6> sm6;
+    const int rounds = (a.nblk + 3) / 4;
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        body_residuals(a, t, acc);
+        fused_wave_part<6, false>(acc, sm6, t.vb);
+    }
+    double tot[6];
+    fused_total<6, false>(sm6, a.nblk, tot);               // (its last barrier: every thread has read S[S_TAU])
+    if (threadIdx.x == 0) scalar_indicators(a, is_init, ip_next, tol, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
 }
 
 // x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
@@ -510,7 +697,17 @@ double refine_below() {
     static const double v = lp_knob("LPIPM_REFINE_BELOW") ? atof(lp_knob("LPIPM_REFINE_BELOW")) : REFINE_BELOW_RHO_MU;
     return v;
 }
+// the fused single-workgroup kernels: single GPU, n and m within FUSED_MAX_NBLK virtual blocks (LPIPM_VEC_FUSED=0: never)
+bool vec_fused(const VecArgs& a) {
+    if (a.gs != nullptr || a.nblk > FUSED_USE_NBLK) return false;
+    const char* e = lp_knob("LPIPM_VEC_FUSED");          // (read per call: the tests switch it inside one process)
+    return !(e && e[0] == '0');
+}
 int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr) {
+    if (vec_fused(a) && !xr) {
+        hipLaunchKernelGGL(k_fused_residuals, sgrid(a), dim3(FUSED_THREADS), 0, st, a, is_init, ip_next, tol);
+        return 0;
+    }
     hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);
     if (int rc = cross(a, xr, 2, 4, 0, -1, 2, 4, st)) return rc;     // |r_D|^2, c.x, x.z, c.(x/tau)
     hipLaunchKernelGGL(k_scalar_indicators, sgrid(a), dim3(64), 0, st, a, is_init, ip_next, tol);
@@ -548,6 +745,12 @@ int vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st) {
     if (folded(a)) hipLaunchKernelGGL(k_corr_setup<true>, vgrid(a), dim3(256), 0, st, a, ip);
     else           hipLaunchKernelGGL(k_corr_setup<false>, vgrid(a), dim3(256), 0, st, a, ip);
+}
+void vec_fused_predictor(const VecArgs& a, int ip, hipStream_t st) {
+    hipLaunchKernelGGL(k_fused_predictor, sgrid(a), dim3(FUSED_THREADS), 0, st, a, ip);
+}
+void vec_fused_corrector(const VecArgs& a, int ip, double alpha0, hipStream_t st) {
+    hipLaunchKernelGGL(k_fused_corrector, sgrid(a), dim3(FUSED_THREADS), 0, st, a, ip, alpha0);
 }
 void vec_step(const VecArgs& a, int ip, double alpha0, hipStream_t st) {
     if (folded(a)) hipLaunchKernelGGL(k_step<true>, vgrid(a), dim3(256), 0, st, a, ip, alpha0);

@@ -1054,9 +1054,12 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 2, v.R, bt));              // :223
     prof_mark(c, T_GEMV);
+    if (!xr && vec_fused(v)) vec_fused_predictor(v, ip, st);   // the three below in one launch (small n)
+    else {
     LP_TRY(vec_pq_uv(v, st, xr));                       // :223, delta.rs:29-32,38
     LP_TRY(vec_delta(v, 0, ip, 1.0, st, xr));           // delta.rs:33-37, feasible_point.rs:134-136
     vec_corr_setup(v, ip, st);              // rhat.rs:37-75
+    }
     prof_mark(c, T_VEC);
     // corrector: only the second sym_solve changes
     if (!c->colsplit) {
@@ -1072,9 +1075,12 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     prof_mark(c, T_TRSV);
     LP_HIP(ctx_gemv_t(c, 1, v.R, bt));
     prof_mark(c, T_GEMV);
+    if (!xr && vec_fused(v)) vec_fused_corrector(v, ip, o->alpha0, st);
+    else {
     LP_TRY(vec_uv_corr(v, st, xr));
     LP_TRY(vec_delta(v, 1, ip, o->alpha0, st, xr));     // mod.rs:216-221
     vec_step(v, ip, o->alpha0, st);         // feasible_point.rs:76-106 (+ the step length, mod.rs:216-221, when folded)
+    }
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
     LP_TRY(copy_status(c));

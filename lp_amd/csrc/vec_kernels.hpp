@@ -72,6 +72,10 @@ int  vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
 int  vec_delta(const VecArgs& a, int phase, int ip, double alpha0, hipStream_t st, const XRank* xr = nullptr);
 void vec_corr_setup(const VecArgs& a, int ip, hipStream_t st);
 void vec_step(const VecArgs& a, int ip, double alpha0, hipStream_t st);
+// one launch for a run of the kernels above (kernels_vec.hip, "fused vector stage"): vec_fused(a) says whether they apply
+bool vec_fused(const VecArgs& a);
+void vec_fused_predictor(const VecArgs& a, int ip, hipStream_t st);                  // vec_pq_uv + vec_delta(0) + vec_corr_setup
+void vec_fused_corrector(const VecArgs& a, int ip, double alpha0, hipStream_t st);   // vec_uv_corr + vec_delta(1) + vec_step
 int  vec_final_x(const VecArgs& a, double* xout, hipStream_t st, const XRank* xr = nullptr);
 // Y[q][i] += add_q[i] (i < m): the addend of a column-split A.w after its cross-rank sum
 // packed has mp*(mp+128)/2 doubles; dir 0 = M -> packed, 1 = packed -> M (mp a multiple of 128, ld even)

@@ -8,8 +8,8 @@ from oracle import capi as oracle
 ctx = lp.default_context(0)
 o = lp.InteriorPoint.default().opts()
 rows = []
-for (m, n) in [(32, 64), (64, 200), (128, 256), (200, 333), (256, 512), (384, 1000), (512, 1024)]:
-    for seed in range(6):
+for (m, n) in [(32, 64), (64, 200), (128, 256), (200, 333), (256, 512), (384, 1000), (512, 1024), (640, 1100), (1024, 2048)]:
+    for seed in range(6 if m <= 512 else 3):
         A, b, c, xs = synth.planted_lp(seed, m, n)
         ctx.upload_arrays(A, b, c)
         rc, x, fun, it, _ = ctx.solve_raw(o)

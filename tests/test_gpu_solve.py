@@ -395,6 +395,28 @@ def test_graph_replay_is_bit_identical(built, monkeypatch):
     assert np.abs(r3[1] - r0[1]).max() < 1e-6
 
 
+@pytest.mark.parametrize("m,n,ip", [(200, 520, False), (512, 1024, False), (1000, 1024, True), (300, 900, True), (7, 13, False)])
+def test_fused_vector_stage_is_bit_identical(built, monkeypatch, m, n, ip):
+    """Up to 1024 rows / columns the runs of vector kernels between the passes over A are ONE single-workgroup launch each
+    (kernels_vec.hip, k_fused_predictor / k_fused_corrector / k_fused_residuals) that rebuilds the reduction tree of the
+    kernel-by-kernel path: every iterate, the log and the iteration count must have the same bits as with
+    LPIPM_VEC_FUSED=0 (rhat.rs:37-75, delta.rs:21-49, feasible_point.rs:53-106, residual.rs:13-44, indicators.rs:37-83)."""
+    import lp_amd
+    from lp_amd import synth
+    A, b, c = synth.planted_lp(4, m, n)[:3]
+    o = lp_amd.InteriorPoint.default().opts()
+    o.ip = 1 if ip else 0
+    fused = lp_amd.Context(0)
+    fused.upload_arrays(A, b, c)
+    r0 = fused.solve_raw(o, want_log=True)
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
+    monkeypatch.setenv("LPIPM_VEC_FUSED", "0")
+    r1 = fused.solve_raw(o, want_log=True)       # (the knob is read per launch)
+    fused.close()
+    assert r0[0] == r1[0] == 0 and r0[3] == r1[3] and r0[2] == r1[2]
+    assert np.array_equal(r0[1], r1[1]) and r0[4] == r1[4]
+
+
 @pytest.mark.parametrize("case", ["dup_rows", "dependent_row", "zero_row"])
 def test_rank_deficient_constraints_are_a_numerical_problem(ctx, case):
     """Linearly dependent rows make A.D.A^T singular: the reference's Cholesky fails and `solve` returns
