@@ -161,8 +161,9 @@ __global__ __launch_bounds__(256) void k_residuals(VecArgs a) {
 // Residuals::calculate + Indicators::from_point_and_problem + Indicators::status
 // (residual.rs:33-43, indicators.rs:37-55, :57-83), then the scalars the NEXT get_delta starts
 // from (feasible_point.rs:119-125, rhat.rs:31,33).
-__device__ __forceinline__ void scalar_indicators(const VecArgs& a, int is_init, int ip_next, double tol, double rp2, double by,
-                                                  double rd2, double cx, double xz, double cxt) {    // ONE thread
+struct NextDelta { double gamma, mu, eta; int finished; };
+__device__ __forceinline__ NextDelta scalar_indicators(const VecArgs& a, int is_init, int ip_next, double tol, double rp2, double by,
+                                                       double rd2, double cx, double xz, double cxt) {    // ONE thread
     double* S = a.S;
     const double tau = S[S_TAU], kappa = S[S_KAPPA];
     const double rho_p = sqrt(rp2);                                   // residual.rs:34
@@ -206,6 +207,7 @@ __device__ __forceinline__ void scalar_indicators(const VecArgs& a, int is_init,
     S[S_RG] = rG; S[S_MU] = mu; S[S_GAMMA] = gamma; S[S_ETA] = eta;
     S[S_RHAT_G] = rG * eta;                                           // rhat.rs:31
     S[S_RHAT_TK] = gamma * mu - tau * kappa;                          // rhat.rs:33
+    return NextDelta{gamma, mu, eta, finished ? 1 : 0};
 }
 __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol) {
     if (!vbatch(a, true)) return;
@@ -215,18 +217,16 @@ __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double 
     const double rd2 = a.gs ? a.gs[2] : fold_sum(a.red, 2, nblk), cx = a.gs ? a.gs[3] : fold_sum(a.red, 3, nblk);
     const double xz = a.gs ? a.gs[4] : fold_sum(a.red, 4, nblk), cxt = a.gs ? a.gs[5] : fold_sum(a.red, 5, nblk);
     if (threadIdx.x != 0) return;
-    scalar_indicators(a, is_init, ip_next, tol, rp2, by, rd2, cx, xz, cxt);
+    (void)scalar_indicators(a, is_init, ip_next, tol, rp2, by, rd2, cx, xz, cxt);
 }
 
 // ---------------------------------------------------------------- predictor set-up
 // newton_equations.rs:54 (Dinv = x/z); rhat.rs:29-32 (predictor r_hat); the r1 argument of the
 // second sym_solve (newton_equations.rs:188: rhat.d - rhat.xs/x) and the Dinv*r1 prologues of both
 // sym_solve calls (:220).
-__global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
-    if (!vbatch(a, true)) return;
-    const int stride = gridDim.x * 256;
-    const double gm = a.S[S_GAMMA] * a.S[S_MU], eta = a.S[S_ETA];
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.n; j += stride) {
+__device__ __forceinline__ void body_pred_setup(const VecArgs& a, const VThread t, double gm, double eta) {
+    const int stride = t.nvb * 256;
+    for (int j = t.vb * 256 + t.vt; j < a.n; j += stride) {
         const double xj = a.x[j], zj = a.z[j];
         const double dinv = xj / zj;
         const double xs = (xj * -1.0) * zj + gm;
@@ -237,6 +237,10 @@ __global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
         a.W[j] = dinv * a.c[j];
         a.W[a.np + j] = dinv * r1;
     }
+}
+__global__ __launch_bounds__(256) void k_pred_setup(VecArgs a) {
+    if (!vbatch(a, true)) return;
+    body_pred_setup(a, plain_thread(), a.S[S_GAMMA] * a.S[S_MU], a.S[S_ETA]);
 }
 
 // sym_solve epilogue u = Dinv*(A^T.v - r1) for both solves of the predictor
@@ -645,10 +649,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_corrector(VecArgs a, in
     }
 }
 
-// k_residuals -> k_scalar_indicators
-__global__ __launch_bounds__(FUSED_THREADS) void k_fused_residuals(VecArgs a, int is_init, int ip_next, double tol) {
+// k_residuals -> k_scalar_indicators [-> k_pred_setup of the next iteration, unless the LP has just finished]
+__global__ __launch_bounds__(FUSED_THREADS) void k_fused_residuals(VecArgs a, int is_init, int ip_next, double tol, int with_pred) {
     if (!vbatch(a, true)) return;
     __shared__ FusedSm<6> sm6;
+    __shared__ NextDelta nd;
     const int rounds = (a.nblk + 3) / 4;
     for (int r = 0; r < rounds; ++r) {
         const VThread t = fused_thread(a, r);
@@ -659,7 +664,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_residuals(VecArgs a, in
     }
     double tot[6];
     fused_total<6, false>(sm6, a.nblk, tot);               // (its last barrier: every thread has read S[S_TAU])
-    if (threadIdx.x == 0) scalar_indicators(a, is_init, ip_next, tol, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+    if (threadIdx.x == 0) nd = scalar_indicators(a, is_init, ip_next, tol, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+    if (!with_pred) return;
+    __syncthreads();
+    if (nd.finished) return;                               // k_pred_setup would have found the done word set
+    const double gm = nd.gamma * nd.mu, eta = nd.eta;
+    for (int r = 0; r < rounds; ++r) {
+        const VThread t = fused_thread(a, r);
+        if (t.vb >= a.nblk) continue;
+        body_pred_setup(a, t, gm, eta);
+    }
 }
 
 // x / tau (interior_point/mod.rs:231,238) and the partials of fun = c.(x/tau) (linear_program.rs:61-63)
@@ -703,9 +717,9 @@ bool vec_fused(const VecArgs& a) {
     const char* e = lp_knob("LPIPM_VEC_FUSED");          // (read per call: the tests switch it inside one process)
     return !(e && e[0] == '0');
 }
-int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr) {
+int vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr, bool with_pred) {
     if (vec_fused(a) && !xr) {
-        hipLaunchKernelGGL(k_fused_residuals, sgrid(a), dim3(FUSED_THREADS), 0, st, a, is_init, ip_next, tol);
+        hipLaunchKernelGGL(k_fused_residuals, sgrid(a), dim3(FUSED_THREADS), 0, st, a, is_init, ip_next, tol, with_pred ? 1 : 0);
         return 0;
     }
     hipLaunchKernelGGL(k_residuals, vgrid(a), dim3(256), 0, st, a);

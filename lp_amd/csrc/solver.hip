@@ -93,6 +93,7 @@ struct lpipm_ctx {
     // context that share its arena (every pointer is LP 0's; a view's launches cover the LPs [bt.first, bt.first + B))
     bool is_view = false;
     int halves_env = 1;                  // LPIPM_HALVES=0: one stream for the whole batch
+    bool pred_done = false;              // the last residual launch also ran the next iteration's k_pred_setup
     std::vector<lpipm_ctx*> halves;
     std::vector<hipEvent_t> ev_ready, ev_chain, ev_adat;
     int refine = 0;              // set from the environment by lpipm_create.  0 (default): plain solves; LPIPM_REFINE=2: every
@@ -949,7 +950,11 @@ static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol)
         LP_HIP(ctx_gemv_t(c, 1, v.y, c->bt));
     }
     prof_mark(c, T_GEMV);
-    LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->st, c->colsplit ? &xr : nullptr));
+    // small LPs: the launch goes on with the next iteration's Dinv / r_hat set-up (enqueue_head then skips it); not under graph
+    // replay, where the head must be the same launches every time
+    const bool with_pred = !c->colsplit && vec_fused(v) && c->use_graph != 1;
+    LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->st, c->colsplit ? &xr : nullptr, with_pred));
+    c->pred_done = with_pred;
     LP_HIP(hipGetLastError());
     return LPIPM_OK;
 }
@@ -976,7 +981,8 @@ static int enqueue_head(lpipm_ctx* c) {
     VecArgs vh = c->va;
     vh.done_chk = c->bt_head.done;
     prof_mark(c, T_VEC);
-    vec_pred_setup(vh, st);
+    if (c->pred_done) c->pred_done = false;       // the residual launch in front of this head has done it (enqueue_residuals)
+    else vec_pred_setup(vh, st);
     if (c->factor_in_head) {   // A.D.A^T and the Cholesky factorisation side by side (newton_equations.rs:55-57, :129-131)
         prof_mark(c, T_VEC);
         LP_TRY(enqueue_factor_grouped(c, c->bt_head));

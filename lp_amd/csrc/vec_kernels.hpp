@@ -65,7 +65,9 @@ struct XRank {
     void* self;
 };
 void vec_blind_start(const VecArgs& a, hipStream_t st);
-int  vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr = nullptr);
+// with_pred (only where vec_fused(a) holds and xr is null): the launch also does vec_pred_setup for the next iteration
+int  vec_residuals(const VecArgs& a, int is_init, int ip_next, double tol, hipStream_t st, const XRank* xr = nullptr,
+                   bool with_pred = false);
 void vec_pred_setup(const VecArgs& a, hipStream_t st);
 int  vec_pq_uv(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
 int  vec_uv_corr(const VecArgs& a, hipStream_t st, const XRank* xr = nullptr);
