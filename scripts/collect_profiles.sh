@@ -28,6 +28,8 @@ cd $REPO
 PMC_LPS_PER_LAUNCH=1 python3 scripts/pmc_summary.py gemm_nt_units 4096 8192 $OUT/${R}_adat_pmc.json /tmp/p_pmc_c3 > /dev/null
 python3 scripts/pmc_summary.py gemv_dual 512 1024 $OUT/${R}_gemv_pmc.json /tmp/p_pmc_c2 > /dev/null
 python3 scripts/pmc_summary.py gemm_nt_units 1024 2048 $OUT/${R}_adat_c4_pmc.json /tmp/p_pmc_c4 > /dev/null
+# the bench line reports the PMC figures only from a summary whose csrc hash matches: put the fresh ones where it looks
+cp $OUT/${R}_adat_pmc.json $OUT/${R}_gemv_pmc.json $OUT/${R}_adat_c4_pmc.json profiles/
 python3 bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
 python3 bench.py --workload c2 --no-cpu-baseline > $OUT/${R}_bench_c2.json 2>> $OUT/${R}_bench.err
 python3 bench.py --workload c4 --steps 5 > $OUT/${R}_bench_c4.json 2>> $OUT/${R}_bench.err
