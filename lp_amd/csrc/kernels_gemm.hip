@@ -635,6 +635,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every arrival of this launch is in: the word goes back to zero for the next launch (the host then needs no
+            // memset per launch; with group words the consumers on other streams make the host clear both kinds)
+            if (!GRP) __hip_atomic_store(p.tile_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         // combine: slabs 0 .. cpt-1 added in chunk order; a thread owns 16 pairs of adjacent elements, 1024 elements apart

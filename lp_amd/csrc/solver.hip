@@ -74,6 +74,8 @@ struct lpipm_ctx {
     unsigned int* tile_cnt = nullptr;    // arena: arrival counters of the tiles, then the group words (one memset clears both)
     unsigned int* grp_cnt = nullptr;
     size_t cnt_bytes = 0;
+    bool cnt_dirty = true;               // the arrival words may be non-zero: the next plain units launch clears them first (a plain
+                                         // launch leaves them zero itself; launches with group words do not)
     unsigned int* wait_timeout = nullptr;   // arena: set by a wait kernel that gave up (a producer that never ran)
     unsigned int* timeout_host = nullptr;   // pinned mirror, read with the status record
     // factorisation beside A.D.A^T (enqueue_factor_grouped): CU-masked streams, column groups of the tile list
@@ -523,8 +525,9 @@ static void plan_adat(lpipm_ctx* c, int count) {
     // 0.55 GB at C3, 38 MB per member at C4) -- up to 4 GiB per LP, beyond that (m = 16384: 34 GB) the round-2 kernel
     c->cpt = adat_units_cpt(c->npa);
     c->units = c->units_env != 0 && (size_t)c->ntiles * c->cpt * TILE * TILE * sizeof(double) <= ((size_t)4 << 30) &&
-               (count > 1 || c->units_env == 2 || c->st_a != nullptr || c->cpt == 1 || c->ntiles * c->cpt >= 256);
-    // (a single LP with few tiles AND several chunks -- 1000x5000: 36 tiles x 3 -- keeps the round-2 kernel: one workgroup per
+               (count > 1 || c->units_env == 2 || c->st_a != nullptr || c->cpt == 1 || c->ntiles <= 16 || c->ntiles * c->cpt >= 256);
+    // (tiny single LPs -- up to 16 tiles -- : one launch and one memset less, 0.042 vs 0.045 ms at 512x1024;
+    //  a single LP with few tiles AND several chunks -- 1000x5000: 36 tiles x 3 -- keeps the round-2 kernel: one workgroup per
     //  tile adding the slabs at the end of a launch that never filled the chip costs more than the 16-way fix-up launch,
     //  0.196 vs 0.151 ms; everywhere else the units kernel is level or ahead -- 4096x8192 2.206 vs 2.22 ms inside a solve,
     //  2048x16384 1.30 vs 1.60 -- carries no spill and leaves out the blocks above the diagonal of the diagonal tiles)
@@ -759,6 +762,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     }
     LP_HIP(hipStreamSynchronize(st));   // the caller's arrays and c0v are free again from here
     c->has_problem = true;
+    c->cnt_dirty = true;
     return LPIPM_OK;
 }
 
@@ -830,8 +834,9 @@ static hipError_t run_adat(lpipm_ctx* c, const Batch& bt) {
     bool second_copy;
     if (c->units) {
         const AdatUnitsArgs a = adat_units_args(c, bt);
-        if (c->cpt > 1 && (e = clear_unit_counters(c, bt, c->st)) != hipSuccess) return e;
+        if (c->cpt > 1 && c->cnt_dirty && (e = clear_unit_counters(c, bt, c->st)) != hipSuccess) return e;
         if ((e = launch_adat_units(a, c->st)) != hipSuccess) return e;
+        c->cnt_dirty = false;            // the last arriver of every tile has put its word back to zero
         second_copy = a.C2 != nullptr;
     } else {
         const GemmArgs g = adat_args(c, bt);
@@ -870,6 +875,7 @@ static int enqueue_factor_grouped(lpipm_ctx* c, const Batch& bt) {
     // the words the other streams poll are cleared BEFORE they are released (a wait kernel that ran ahead of the memset
     // would see the previous iteration's full counts)
     LP_HIP(clear_unit_counters(c, bt, sm));
+    c->cnt_dirty = true;
     LP_HIP(hipEventRecord(c->ev_fork, sm));
     LP_HIP(hipStreamWaitEvent(sa, c->ev_fork, 0));
     LP_HIP(hipStreamWaitEvent(su, c->ev_fork, 0));
@@ -1001,6 +1007,7 @@ static int enqueue_head(lpipm_ctx* c) {
         hipStream_t sc = c->st_c;
         const Batch& bt = c->bt_head;
         LP_HIP(clear_unit_counters(c, bt, st));
+        c->cnt_dirty = true;
         LP_HIP(hipEventRecord(c->ev_c0, st));
         LP_HIP(hipStreamWaitEvent(sc, c->ev_c0, 0));
         AdatUnitsArgs a = adat_units_args(c, bt);
@@ -1281,6 +1288,7 @@ static void destroy_views(lpipm_ctx* c) {
 static lpipm_ctx* make_view(const lpipm_ctx* c, int first, int count) {
     lpipm_ctx* v = new lpipm_ctx(*c);
     v->is_view = true;
+    v->cnt_dirty = true;
     v->halves.clear(); v->workers.clear(); v->graphs.clear(); v->kallocs.clear();
     v->events.clear(); v->mark_tags.clear(); v->nmarks = 0;
     v->ev_ready.clear(); v->ev_chain.clear(); v->ev_adat.clear(); v->la = PotrfLookahead{};

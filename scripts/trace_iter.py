@@ -1,10 +1,12 @@
 """Every kernel of ONE iteration (between two k_pred_setup launches in the middle of the last solve) from a rocprofv3
---kernel-trace CSV: start, end (us from the iteration's start), queue, grid, name.  usage: trace_iter.py trace.csv [which=-3]"""
+--kernel-trace CSV: start, end (us from the iteration's start), queue, grid, name.
+usage: trace_iter.py trace.csv [which=-3] [marker=k_pred_setup]   (small LPs have no k_pred_setup launch: use k_fused_residuals)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
-starts = [i for i, r in enumerate(rows) if "k_pred_setup" in r["Kernel_Name"]]
+marker = sys.argv[3] if len(sys.argv) > 3 else "k_pred_setup"
+starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 i0, i1 = starts[which], starts[which + 1]
 t0 = int(rows[i0]["Start_Timestamp"])
 busy = {}
