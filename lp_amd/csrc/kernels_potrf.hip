@@ -719,8 +719,8 @@ hipError_t potrf_superblock_inverses(const FactorPlan& plan, hipStream_t st, con
 }
 
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
-                        const Batch& bt, const PotrfLookahead* la) {
-    hipError_t e = potrf_clear_info(info, st, bt);
+                        const Batch& bt, const PotrfLookahead* la, bool clear_info) {
+    hipError_t e = clear_info ? potrf_clear_info(info, st, bt) : hipSuccess;   // (the solver's iteration keeps the word clean itself)
     if (e != hipSuccess) return e;
     const int nb = mp / NB;
     // Look-ahead (one LP, enough trailing matrix for it to matter): behind outer panel p the block columns of panel p+1 are

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void k_blind_start(VecArgs a) {
         a.S[S_KAPPA] = 1.0;
         *a.flags = 0;
         *a.done = 0;
+        *a.potrf_info = 0;
     }
 }
 
@@ -198,6 +199,7 @@ __device__ __forceinline__ NextDelta scalar_indicators(const VecArgs& a, int is_
     // what ends the loop of solve_normal_form (mod.rs:215, :231-233): from here on the LP's kernels are skipped
     const bool finished = !is_init && (status != ST_UNFINISHED || *a.potrf_info != 0 || (*a.flags & FLAG_NAN_PQ));
     if (finished) *a.done = 1;
+    *a.potrf_info = 0;      // read and recorded: the next factorisation starts from a clean word (launch_potrf need not clear it)
     *a.skip_refine = (finished || !(imu <= a.refine_below)) ? 1 : 0;
     // next get_delta (feasible_point.rs:119-125)
     const double gamma = ip_next ? 1.0 : 0.0;

@@ -216,7 +216,7 @@ struct PotrfLookahead {
     int min_nb = 32;         // 128-blocks from which the look-ahead is used (default: m >= 4096; LPIPM_LOOKAHEAD=1: 12)
 };
 hipError_t launch_potrf(double* M, int64_t ld, int mp, const FactorPlan& plan, int32_t* info, hipStream_t st,
-                        const Batch& bt = Batch{}, const PotrfLookahead* la = nullptr);
+                        const Batch& bt = Batch{}, const PotrfLookahead* la = nullptr, bool clear_info = true);
 
 // The pieces of launch_potrf, for the factorisation that runs beside A.D.A^T (solver.hip, enqueue_factor_overlapped):
 constexpr int POTRF_OUTER = 4;   // 128-blocks per outer panel

@@ -1050,7 +1050,8 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     const Batch& bt = c->bt;
     const bool chol = o->solver_type == LPIPM_SOLVER_CHOLESKY;
     if (c->factor_in_head) {}                                                             // factorised beside A.D.A^T
-    else if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt, lookahead(c)));   // :129-131
+    // (no clearing of the pivot-failure word: k_blind_start and every k_scalar_indicators leave it zero)
+    else if (chol) LP_HIP(launch_potrf(c->M, c->mp, c->mp, c->plan, v.potrf_info, st, bt, lookahead(c), false));   // :129-131
     else           LP_HIP(launch_qr_factor(c->M, c->mp, c->mp, c->tau, v.potrf_info, st));   // :133-149
     prof_mark(c, T_POTRF);
     // predictor: both sym_solve calls of solve_newton_equations (:187-188) in one pass each
