@@ -12,8 +12,13 @@
 //   solver.solve(&problem)? -> OptimizeResult              solver.solve(problem) -> OptimizeResult
 //   res.x() / res.fun() / res.iteration()                  res.x() / res.fun() / res.iteration()
 //
-// Matrices are row-major std::vector<double> + (rows, cols), the layout ndarray gives `Problem`.
+// Matrices are row-major std::vector<F> + (rows, cols), the layout ndarray gives `Problem`.
+// The reference is generic over `F: Float` (src/float.rs:8-43, f64 and f32): the classes below are templates over the
+// scalar type with the f64 instantiation under the reference's plain names (Problem, Matrix, OptimizeResult) and the f32 one
+// as ProblemF32 / MatrixF32 / OptimizeResultF32; InteriorPoint::solve takes either (f64: the hand-written fp64 path,
+// f32: lpipm_solve_f32).
 #pragma once
+#include <type_traits>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -60,83 +65,109 @@ inline void raise_for(int status, std::vector<double> x = {}) {
     throw LinearProgramError(static_cast<ErrorKind>(status), msg, std::move(x));
 }
 
-struct Matrix {  // row-major, the layout of ndarray's standard Array2
-    std::vector<double> data;
+template <class F> struct BasicMatrix {  // row-major, the layout of ndarray's standard Array2
+    static_assert(std::is_same<F, double>::value || std::is_same<F, float>::value, "src/float.rs:33-43: f64 and f32");
+    std::vector<F> data;
     uint64_t rows = 0, cols = 0;
 };
 
-class ProblemBuilder;
+template <class F> class BasicProblemBuilder;
 
 // src/linear_program.rs:24-70
-class Problem {
+template <class F> class BasicProblem {
 public:
-    static ProblemBuilder target(const std::vector<double>& c);  // :37-39
-    const Matrix& A() const { return A_; }                       // :42-44
-    const std::vector<double>& b() const { return b_; }          // :47-49
-    const std::vector<double>& c() const { return c_; }          // :52-54
-    double c0() const { return c0_; }                            // :57-59
+    static BasicProblemBuilder<F> target(const std::vector<F>& c);   // :37-39
+    const BasicMatrix<F>& A() const { return A_; }                   // :42-44
+    const std::vector<F>& b() const { return b_; }                   // :47-49
+    const std::vector<F>& c() const { return c_; }                   // :52-54
+    F c0() const { return c0_; }                                     // :57-59
     uint64_t n_slack() const { return n_slack_; }
-    std::vector<double> denormalize_x_into(std::vector<double> x_slack) const {  // :65-69
+    std::vector<F> denormalize_x_into(std::vector<F> x_slack) const {  // :65-69
         x_slack.resize(x_slack.size() - n_slack_);
         return x_slack;
     }
 
 private:
-    friend class ProblemBuilder;
-    Matrix A_;
-    std::vector<double> b_, c_;
-    double c0_ = 0.0;
+    friend class BasicProblemBuilder<F>;
+    BasicMatrix<F> A_;
+    std::vector<F> b_, c_;
+    F c0_ = 0;
     uint64_t n_slack_ = 0;
 };
 
 // src/linear_program.rs:72-170
-class ProblemBuilder {
+template <class F> class BasicProblemBuilder {
 public:
-    explicit ProblemBuilder(const std::vector<double>& c) : c_(c) {}
-    ProblemBuilder& ub(const Matrix& A, const std::vector<double>& b) { ub_A_ = &A; ub_b_ = &b; return *this; }  // :93-96
-    ProblemBuilder& eq(const Matrix& A, const std::vector<double>& b) { eq_A_ = &A; eq_b_ = &b; return *this; }  // :102-105
-    Problem build() const {                                                                                       // :125-169
+    explicit BasicProblemBuilder(const std::vector<F>& c) : c_(c) {}
+    BasicProblemBuilder& ub(const BasicMatrix<F>& A, const std::vector<F>& b) { ub_A_ = &A; ub_b_ = &b; return *this; }  // :93-96
+    BasicProblemBuilder& eq(const BasicMatrix<F>& A, const std::vector<F>& b) { eq_A_ = &A; eq_b_ = &b; return *this; }  // :102-105
+    BasicProblem<F> build() const {                                                                               // :125-169
         const uint64_t n = c_.size();
         const uint64_t m_ub = ub_A_ ? ub_A_->rows : 0, m_eq = eq_A_ ? eq_A_->rows : 0;
         if (m_ub + m_eq == 0) raise_for(LPIPM_UNCONSTRAINED);                                                     // :134-136
         if ((ub_A_ && (ub_A_->cols != n || ub_b_->size() != m_ub || ub_A_->data.size() != m_ub * n)) ||
             (eq_A_ && (eq_A_->cols != n || eq_b_->size() != m_eq || eq_A_->data.size() != m_eq * n)))
             raise_for(LPIPM_INCOMPATIBLE_DIMENSIONS);                                                             // :137-143
-        Problem p;
+        BasicProblem<F> p;
         p.A_.rows = m_ub + m_eq;
         p.A_.cols = n + m_ub;
-        p.A_.data.resize(p.A_.rows * p.A_.cols);
+        p.A_.data.assign(p.A_.rows * p.A_.cols, F(0));
         p.b_.resize(p.A_.rows);
-        p.c_.resize(p.A_.cols);
-        raise_for(lpipm_problem_build(n, m_ub, ub_A_ ? ub_A_->data.data() : nullptr, ub_b_ ? ub_b_->data() : nullptr,
-                                      m_eq, eq_A_ ? eq_A_->data.data() : nullptr, eq_b_ ? eq_b_->data() : nullptr,
-                                      c_.data(), p.A_.data.data(), p.b_.data(), p.c_.data(), &p.n_slack_));
+        p.c_.assign(p.A_.cols, F(0));
+        if constexpr (std::is_same<F, double>::value) {
+            raise_for(lpipm_problem_build(n, m_ub, ub_A_ ? ub_A_->data.data() : nullptr, ub_b_ ? ub_b_->data() : nullptr,
+                                          m_eq, eq_A_ ? eq_A_->data.data() : nullptr, eq_b_ ? eq_b_->data() : nullptr,
+                                          c_.data(), p.A_.data.data(), p.b_.data(), p.c_.data(), &p.n_slack_));
+        } else {
+            // the slack form of linear_program.rs:145-160 (the C ABI's lpipm_problem_build is the f64 instantiation):
+            //   A = [[A_ub, I], [A_eq, 0]], b = [b_ub; b_eq], c = [c; 0]
+            const uint64_t nn = p.A_.cols;
+            for (uint64_t i = 0; i < m_ub; ++i) {
+                for (uint64_t j = 0; j < n; ++j) p.A_.data[i * nn + j] = ub_A_->data[i * n + j];
+                p.A_.data[i * nn + n + i] = F(1);
+                p.b_[i] = (*ub_b_)[i];
+            }
+            for (uint64_t i = 0; i < m_eq; ++i) {
+                for (uint64_t j = 0; j < n; ++j) p.A_.data[(m_ub + i) * nn + j] = eq_A_->data[i * n + j];
+                p.b_[m_ub + i] = (*eq_b_)[i];
+            }
+            for (uint64_t j = 0; j < n; ++j) p.c_[j] = c_[j];
+            p.n_slack_ = m_ub;
+        }
         return p;
     }
 
 private:
-    const std::vector<double>& c_;
-    const Matrix* ub_A_ = nullptr;
-    const std::vector<double>* ub_b_ = nullptr;
-    const Matrix* eq_A_ = nullptr;
-    const std::vector<double>* eq_b_ = nullptr;
+    const std::vector<F>& c_;
+    const BasicMatrix<F>* ub_A_ = nullptr;
+    const std::vector<F>* ub_b_ = nullptr;
+    const BasicMatrix<F>* eq_A_ = nullptr;
+    const std::vector<F>* eq_b_ = nullptr;
 };
-inline ProblemBuilder Problem::target(const std::vector<double>& c) { return ProblemBuilder(c); }
+template <class F> inline BasicProblemBuilder<F> BasicProblem<F>::target(const std::vector<F>& c) { return BasicProblemBuilder<F>(c); }
 
 // src/solvers/mod.rs:19-49
-class OptimizeResult {
+template <class F> class BasicOptimizeResult {
 public:
-    OptimizeResult(std::vector<double> x, double fun, uint64_t iteration)
-        : x_(std::move(x)), fun_(fun), iteration_(iteration) {}
+    BasicOptimizeResult(std::vector<F> x, F fun, uint64_t iteration) : x_(std::move(x)), fun_(fun), iteration_(iteration) {}
     uint64_t iteration() const { return iteration_; }
-    double fun() const { return fun_; }
-    const std::vector<double>& x() const { return x_; }
+    F fun() const { return fun_; }
+    const std::vector<F>& x() const { return x_; }
 
 private:
-    std::vector<double> x_;
-    double fun_;
+    std::vector<F> x_;
+    F fun_;
     uint64_t iteration_;
 };
+
+using Matrix = BasicMatrix<double>;                 // the reference's Problem<f64>, ...
+using Problem = BasicProblem<double>;
+using ProblemBuilder = BasicProblemBuilder<double>;
+using OptimizeResult = BasicOptimizeResult<double>;
+using MatrixF32 = BasicMatrix<float>;               // ... and Problem<f32>
+using ProblemF32 = BasicProblem<float>;
+using ProblemBuilderF32 = BasicProblemBuilder<float>;
+using OptimizeResultF32 = BasicOptimizeResult<float>;
 
 enum class EquationSolverType { Cholesky = 0, Inverse = 1, LeastSquares = 2 };  // newton_equations.rs:37-46
 
@@ -187,6 +218,22 @@ public:
         if (rc == LPIPM_ITERATION_LIMIT) raise_for(rc, x);          // payload: x / tau, mod.rs:237-239
         raise_for(rc);
         return OptimizeResult(problem.denormalize_x_into(std::move(x)), fun, it);  // mod.rs:165-167
+    }
+    // The f32 instantiation of the same `solve` (src/float.rs:42-43): every operation in f32, lpipm_solve_f32.  With the
+    // default tol = 1e-8 an f32 solve cannot satisfy the optimality test (the reference's behaviour): pass 1e-4 .. 1e-5.
+    OptimizeResultF32 solve(const ProblemF32& problem) const {
+        lpipm_ctx* ctx = nullptr;
+        raise_for(lpipm_create(device_, &ctx));
+        struct Guard { lpipm_ctx* c; ~Guard() { lpipm_destroy(c); } } guard{ctx};
+        const MatrixF32& A = problem.A();
+        std::vector<float> x(A.cols);
+        float fun = 0.0f;
+        uint64_t it = 0;
+        const int rc = lpipm_solve_f32(ctx, A.rows, A.cols, A.data.data(), A.cols, problem.b().data(), problem.c().data(),
+                                       problem.c0(), &o_, x.data(), &fun, &it, nullptr);
+        if (rc == LPIPM_ITERATION_LIMIT) raise_for(rc, std::vector<double>(x.begin(), x.end()));
+        raise_for(rc);
+        return OptimizeResultF32(problem.denormalize_x_into(std::move(x)), fun, it);
     }
 
 private:

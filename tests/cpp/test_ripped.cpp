@@ -108,9 +108,38 @@ static void gpu_tests() {
     }
 }
 
+// The reference is generic over F: Float (src/float.rs:42-43); it holds no f32 test, so these restate lib.rs:84-113 in f32
+// at a tolerance f32 can reach ("parity unpinned" by the reference; the f32 oracle is the checker in tests/test_gpu_f32.py).
+static ProblemF32 make_problem_f32() {
+    static const MatrixF32 A_ub{{-3, 1, 1, 2}, 2, 2}, A_eq{{1, 1}, 1, 2};
+    static const std::vector<float> b_ub{6, 4}, b_eq{1}, c{-1, 4};
+    return ProblemF32::target(c).ub(A_ub, b_ub).eq(A_eq, b_eq).build();
+}
+static void host_tests_f32() {
+    ProblemF32 p = make_problem_f32();
+    CHECK(p.A().rows == 3 && p.A().cols == 4 && p.n_slack() == 2 && p.c0() == 0.0f);
+    const std::vector<float> want{-3, 1, 1, 0, 1, 2, 0, 1, 1, 1, 0, 0};
+    CHECK(p.A().data == want);
+    CHECK((p.b() == std::vector<float>{6, 4, 1}) && (p.c() == std::vector<float>{-1, 4, 0, 0}));
+    std::vector<float> c{1, 2};
+    try { ProblemF32::target(c).build(); CHECK(false); }
+    catch (const LinearProgramError& e) { CHECK(e.kind() == ErrorKind::Unconstrained); }
+}
+static void gpu_tests_f32() {
+    OptimizeResultF32 res = InteriorPoint::custom().tol(1e-4).build().solve(make_problem_f32());
+    CHECK(res.x().size() == 2 && std::fabs(res.x()[0] - 1.0f) < 1e-3f && std::fabs(res.x()[1]) < 1e-3f);
+    CHECK(std::fabs(res.fun() + 1.0f) < 1e-3f && res.iteration() >= 3 && res.iteration() <= 20);
+    // at the default tolerance the f32 instantiation cannot pass the optimality test (6e-8 is f32's epsilon)
+    try { InteriorPoint::custom().max_iter(40).build().solve(make_problem_f32()); CHECK(false); }
+    catch (const LinearProgramError& e) {
+        CHECK(e.kind() == ErrorKind::NumericalProblem || e.kind() == ErrorKind::IterationLimitExceeded);
+    }
+}
+
 int main(int argc, char** argv) {
     host_tests();
-    if (argc > 1 && !std::strcmp(argv[1], "gpu")) gpu_tests();
+    host_tests_f32();
+    if (argc > 1 && !std::strcmp(argv[1], "gpu")) { gpu_tests(); gpu_tests_f32(); }
     std::printf(failures ? "%d FAILED\n" : "all ok\n", failures);
     return failures ? 1 : 0;
 }
