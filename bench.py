@@ -181,6 +181,7 @@ def main():
             keep = ("metric", "value", "unit", "ms_per_step", "config", "roofline")
             out["c2"] = {k: c2[k] for k in keep}
             out["c2"]["phase_ms_per_iteration"] = c2["phase_ms_per_iteration"]
+            out["c2"]["unbracketed"] = c2.get("unbracketed")
             out["c4"] = {k: c4[k] for k in keep}
             out["c4"]["phase_ms_per_lockstep_iteration"] = c4["phase_ms_per_lockstep_iteration"]
             out["c4"]["parity_rank0"] = c4["parity_rank0"]
@@ -249,6 +250,20 @@ def measure_single(m, n, steps, warmup, c2, want_cpu_baseline, rank, local_rank,
     phase = {k: pt[k] for k in phase}
     phase_iters = max(int(pt["iterations"]), 1)
     ctx.set_profiling(0)
+    # config 2 is a chain of ~30 launches of 5-30 us per iteration: the event brackets of its phase split cost a visible share
+    # of it.  The same steps once more with no event recorded at all (every rank runs them: the step holds the gather)
+    unbracketed = None
+    if c2:
+        barrier()
+        t1 = time.perf_counter()
+        its_u = 0
+        for _ in range(steps):
+            its_u += one_step()[0]
+        barrier()
+        dt_u = time.perf_counter() - t1
+        unbracketed = {"value": its_u / dt_u, "unit": "iterations/s (this rank)", "ms_per_step": dt_u * 1e3 / steps,
+                       "ms_per_iteration": dt_u * 1e3 / max(its_u, 1),
+                       "note": "the same steps with profiling off: no HIP event recorded inside a solve"}
 
     # parity guard on what was just timed: the planted vertex is the known answer
     err = float((x_dev.cpu().numpy() - xstar).__abs__().max())
@@ -323,6 +338,8 @@ def measure_single(m, n, steps, warmup, c2, want_cpu_baseline, rank, local_rank,
         "roofline": roofline,
         "phase_ms_per_iteration": {k: v / phase_iters for k, v in phase.items()},
     }
+    if unbracketed is not None:
+        out["unbracketed"] = unbracketed
     if want_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, b, c, m, n)
     return out

@@ -113,6 +113,8 @@ struct lpipm_ctx {
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
     StatusRec* status_host = nullptr;  // pinned, status_cap records
+    double* x_pinned = nullptr;        // pinned bounce buffer of the solution (a D2H copy into the caller's pageable array takes
+    size_t x_pinned_cap = 0;           //   the runtime's staged path: ~40 us more per solve than pinned + memcpy)
     size_t status_cap = 0;
     // stand-alone potrf/solve buffers
     double *kM = nullptr, *kM0 = nullptr, *kR = nullptr, *kY = nullptr;
@@ -426,6 +428,7 @@ extern "C" void lpipm_destroy(lpipm_ctx* c) {
     if (c->ev_adat_done) (void)hipEventDestroy(c->ev_adat_done);
     if (c->timeout_host) (void)hipHostFree(c->timeout_host);
     if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->x_pinned) (void)hipHostFree(c->x_pinned);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -1171,8 +1174,13 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));  // feasible_point.rs:32, mod.rs:206
     LP_TRY(copy_status(c));
     prof_mark(c, T_VEC);
-    LP_HIP(hipStreamSynchronize(st));
-    prof_collect(c);
+    // the host needs the starting point's indicators only for the `disp` table, for the selective refinement's first decision
+    // and for the phase marks: otherwise the first iteration is enqueued without a round trip to the host (~25 us per solve)
+    const bool need_start_row = o->disp || c->refine == 1 || c->profiling;
+    if (need_start_row) {
+        LP_HIP(hipStreamSynchronize(st));
+        prof_collect(c);
+    }
     if (o->disp) {                                        // mod.rs:208-211
         printf("alpha     \trho_p     \trho_d     \trho_g     \trho_mu    \tobj       \n");
         print_row(1.0, *c->status_host);
@@ -1229,10 +1237,19 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
         LP_TRY(vec_final_x(v, c->xout, st, c->colsplit ? &xrf : nullptr));   // mod.rs:231/238, :165
         LP_HIP(hipGetLastError());
         if (x_dev) LP_HIP(hipMemcpyAsync(x_dev, c->xout, c->n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (x_host) LP_HIP(hipMemcpyAsync(x_host, c->xout, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (x_host) {   // through a pinned buffer: truly asynchronous, one synchronisation for x and the status record
+            if (c->x_pinned_cap < c->n) {
+                if (c->x_pinned) (void)hipHostFree(c->x_pinned);
+                c->x_pinned = nullptr; c->x_pinned_cap = 0;
+                LP_HIP(hipHostMalloc((void**)&c->x_pinned, c->n * sizeof(double)));
+                c->x_pinned_cap = c->n;
+            }
+            LP_HIP(hipMemcpyAsync(c->x_pinned, c->xout, c->n * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
         LP_TRY(copy_status(c));
         if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
         LP_HIP(hipStreamSynchronize(st));
+        if (x_host) std::memcpy(x_host, c->x_pinned, c->n * sizeof(double));
         if (fun_out) *fun_out = c->status_host->obj;
     } else {
         if (c->profiling) LP_HIP(hipEventRecord(c->ev_end, st));
@@ -1295,6 +1312,7 @@ static lpipm_ctx* make_view(const lpipm_ctx* c, int first, int count) {
     v->ev_ready.clear(); v->ev_chain.clear(); v->ev_adat.clear(); v->la = PotrfLookahead{};
     v->st = nullptr; v->st_a = v->st_b = v->st_u = nullptr; v->ev_fork = v->ev_adat_done = nullptr; v->overlap = false;
     v->ev_begin = v->ev_end = v->ev_status = nullptr; v->status_host = nullptr; v->timeout_host = nullptr;
+    v->x_pinned = nullptr; v->x_pinned_cap = 0;
     v->mpack = nullptr; v->kM = v->kM0 = v->kR = v->kY = nullptr; v->kmp = 0; v->kplan = FactorPlan{};
     v->profiling = 0;
     v->B = count;
@@ -1394,8 +1412,10 @@ static int solve_lockstep_one(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo,
     prof_mark(c, T_VEC);
     LP_TRY(enqueue_residuals(c, 1, o->ip ? 1 : 0, o->tol));                  // feasible_point.rs:32, mod.rs:206
     prof_mark(c, T_VEC);
-    LP_HIP(hipStreamSynchronize(st));
-    prof_collect(c);
+    if (c->profiling) {                  // (nothing of the starting point is read by the host otherwise)
+        LP_HIP(hipStreamSynchronize(st));
+        prof_collect(c);
+    }
     std::vector<int> ret((size_t)B, -1);                                     // -1: still iterating
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
