@@ -209,6 +209,15 @@ __device__ __forceinline__ NextDelta scalar_indicators(const VecArgs& a, int is_
     S[S_RG] = rG; S[S_MU] = mu; S[S_GAMMA] = gamma; S[S_ETA] = eta;
     S[S_RHAT_G] = rG * eta;                                           // rhat.rs:31
     S[S_RHAT_TK] = gamma * mu - tau * kappa;                          // rhat.rs:33
+    st->pad_ = a.status_seq;
+    if (a.status_pinned) {       // the record straight into the host's array: payload, system fence, then the sequence word
+        StatusRec* h = a.status_pinned + blockIdx.z;
+        h->alpha = st->alpha; h->rho_p = st->rho_p; h->rho_d = st->rho_d; h->rho_A = st->rho_A; h->rho_g = st->rho_g;
+        h->rho_mu = st->rho_mu; h->obj = st->obj; h->tau = st->tau; h->kappa = st->kappa;
+        h->status = st->status; h->potrf_info = st->potrf_info; h->flags = st->flags;
+        __threadfence_system();
+        __hip_atomic_store(&h->pad_, (int32_t)a.status_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return NextDelta{gamma, mu, eta, finished ? 1 : 0};
 }
 __global__ void k_scalar_indicators(VecArgs a, int is_init, int ip_next, double tol) {
@@ -695,7 +704,10 @@ __global__ __launch_bounds__(256) void k_final_x(VecArgs a, double* xout) {
 __global__ void k_scalar_fun(VecArgs a) {
     if (!vbatch(a, false)) return;
     const double s = a.gs ? a.gs[0] : fold_sum(a.red, 0, a.nblk);
-    if (threadIdx.x == 0) a.status->obj = s + a.S[S_C0];
+    if (threadIdx.x == 0) {
+        a.status->obj = s + a.S[S_C0];
+        if (a.status_pinned) { a.status_pinned[blockIdx.z].obj = s + a.S[S_C0]; __threadfence_system(); }   // (the host synchronises the stream behind this)
+    }
 }
 
 // ---------------------------------------------------------------- launchers

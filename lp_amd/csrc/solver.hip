@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include "vec_kernels.hpp"
 
 using namespace lpipm;
@@ -113,6 +114,8 @@ struct lpipm_ctx {
     int ntiles = 0, adat_nwg = 1;
     VecArgs va{};
     StatusRec* status_host = nullptr;  // pinned, status_cap records
+    uint32_t seq_counter = 0;          // sequence numbers of the status records (VecArgs::status_seq)
+    bool spin_status = false;          // this solve waits for an iteration by watching the records' sequence words (wait_status)
     double* x_pinned = nullptr;        // pinned bounce buffer of the solution (a D2H copy into the caller's pageable array takes
     size_t x_pinned_cap = 0;           //   the runtime's staged path: ~40 us more per solve than pinned + memcpy)
     size_t status_cap = 0;
@@ -307,7 +310,7 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&c->status_host, sizeof(StatusRec)) != hipSuccess ||
+        hipHostMalloc((void**)&c->status_host, sizeof(StatusRec), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
         hipEventCreate(&c->ev_begin) != hipSuccess || hipEventCreate(&c->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_status, hipEventDisableTiming) != hipSuccess) {
         g_err_detail = "failed to create stream / pinned status / events";
@@ -330,6 +333,7 @@ extern "C" int lpipm_create(int device, lpipm_ctx** out) {
         return LPIPM_ERR_HIP;
     }
     *c->timeout_host = 0;
+    std::memset(c->status_host, 0, sizeof(StatusRec));
     // CU-masked streams for the factorisation that runs beside A.D.A^T (enqueue_factor_grouped).  Mask bit i is CU i/8 of
     // XCC i%8 (scripts/diag/cu_mask_probe.cpp; an XCC with no bit set would be unrestricted): the chain stream (st_b) gets
     // CUs 0..R-1 of every XCC -- a diagonal-block kernel needs a whole CU's LDS, and on a chip full of A.D.A^T workgroups it
@@ -549,6 +553,7 @@ static void plan_adat(lpipm_ctx* c, int count) {
 
 // Per-LP device state: one pass over a measuring arena sizes it, a second pass over the real one places it.
 // Every LP of a lockstep batch gets the same layout, `bstride` bytes after the previous LP's.
+static void bind_status_pinned(lpipm_ctx* c, bool allow);
 static int layout_problem(lpipm_ctx* c, Arena& ar, bool build) {
     VecArgs& v = c->va;
     const size_t mp = (size_t)c->mp, np = (size_t)c->np;
@@ -716,7 +721,8 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
         if ((size_t)count > c->status_cap) {
             if (c->status_host) (void)hipHostFree(c->status_host);
             c->status_host = nullptr; c->status_cap = 0;
-            LP_HIP(hipHostMalloc((void**)&c->status_host, (size_t)count * sizeof(StatusRec)));
+            LP_HIP(hipHostMalloc((void**)&c->status_host, (size_t)count * sizeof(StatusRec), hipHostMallocCoherent | hipHostMallocMapped));
+            std::memset(c->status_host, 0, (size_t)count * sizeof(StatusRec));
             c->status_cap = (size_t)count;
         }
         VecArgs& v = c->va;
@@ -766,6 +772,7 @@ static int upload_impl(lpipm_ctx* c, int count, uint64_t m, uint64_t n, const do
     LP_HIP(hipStreamSynchronize(st));   // the caller's arrays and c0v are free again from here
     c->has_problem = true;
     c->cnt_dirty = true;
+    bind_status_pinned(c, true);
     return LPIPM_OK;
 }
 
@@ -961,6 +968,7 @@ static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol)
     prof_mark(c, T_GEMV);
     // small LPs: the launch goes on with the next iteration's Dinv / r_hat set-up (enqueue_head then skips it); not under graph
     // replay, where the head must be the same launches every time
+    v.status_seq = (int)(++c->seq_counter & 0x7fffffffu);
     const bool with_pred = !c->colsplit && vec_fused(v) && c->use_graph != 1;
     LP_TRY(vec_residuals(v, is_init, ip_next, tol, c->st, c->colsplit ? &xr : nullptr, with_pred));
     c->pred_done = with_pred;
@@ -969,8 +977,44 @@ static int enqueue_residuals(lpipm_ctx* c, int is_init, int ip_next, double tol)
 }
 
 // status records of all LPs of the context -> pinned host array (96 bytes each)
+// The status records go straight from the kernels that write them into the context's coherent pinned array
+// (VecArgs::status_pinned: payload, system fence, sequence word), and a solve that needs nothing else from the stream at
+// that point waits for an iteration by watching the sequence words (wait_status): neither a D2H copy launch nor an event
+// record sits between the indicators and the next iteration's A.D.A^T (C2: 4 + 6 us of ~310 per iteration).
+// LPIPM_STATUS_COPY=1: copy launch + event as in rounds 1-2.
+static void bind_status_pinned(lpipm_ctx* c, bool allow) {
+    void* dp = nullptr;
+    const char* e = lp_knob("LPIPM_STATUS_COPY");
+    const bool on = allow && !(e && e[0] == '1') && c->status_host && hipHostGetDevicePointer(&dp, c->status_host, 0) == hipSuccess;
+    (void)hipGetLastError();
+    c->va.status_pinned = on ? (StatusRec*)dp : nullptr;
+}
+// Waits until the records of the LPs `idx[0 .. count)` (nullptr: record 0) carry the sequence number of the last residual
+// launch.  Spins on the pinned records (bounded: ~10 s, then the stream is drained and the records are checked once more).
+static int wait_status(lpipm_ctx* c, const int* idx, int count) {
+    if (!c->spin_status) { LP_HIP(hipEventSynchronize(c->ev_status)); return LPIPM_OK; }
+    const int32_t want = (int32_t)c->va.status_seq;
+    auto arrived = [&]() {
+        for (int k = 0; k < count; ++k) {
+            const StatusRec* r = c->status_host + (idx ? idx[k] : 0);
+            if (__atomic_load_n(&r->pad_, __ATOMIC_ACQUIRE) != want) return false;
+        }
+        return true;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (arrived()) return LPIPM_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xffffu) == 0xffffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+    }
+    LP_HIP(hipStreamSynchronize(c->st));
+    if (arrived()) return LPIPM_OK;
+    g_err_detail = "the status record of an iteration never reached the host";
+    return LPIPM_ERR_HIP;
+}
 static int copy_status(lpipm_ctx* c) {
-    if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, (const char*)c->va.status + (size_t)c->bt.first * c->bstride, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
+    if (c->va.status_pinned) {}          // written by the kernels themselves
+    else if (c->B == 1) LP_HIP(hipMemcpyAsync(c->status_host, (const char*)c->va.status + (size_t)c->bt.first * c->bstride, sizeof(StatusRec), hipMemcpyDeviceToHost, c->st));
     else LP_HIP(hipMemcpy2DAsync(c->status_host, sizeof(StatusRec), (const char*)c->va.status + (size_t)c->bt.first * c->bstride, c->bstride,
                                  sizeof(StatusRec), (size_t)c->B, hipMemcpyDeviceToHost, c->st));
     if (c->factor_in_head || (c->colsplit && c->grouped_reduce))   // a wait kernel that gave up (its producer never ran) says so here
@@ -1102,7 +1146,7 @@ static int enqueue_tail(lpipm_ctx* c, int ip, const lpipm_opts* o) {
     LP_TRY(enqueue_residuals(c, 0, 0, o->tol));   // mod.rs:225
     LP_TRY(copy_status(c));
     prof_mark(c, T_VEC);
-    LP_HIP(hipEventRecord(c->ev_status, st));
+    if (!c->spin_status) LP_HIP(hipEventRecord(c->ev_status, st));
     return LPIPM_OK;
 }
 
@@ -1192,6 +1236,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     // the head of iteration k+1 goes out before the status of iteration k is read (see enqueue_head); not when the
     // iteration is replayed as a graph or contains host-side collectives
     const bool speculate = c->use_graph != 1 && !c->colsplit && !c->no_speculate;
+    c->spin_status = speculate && c->va.status_pinned != nullptr && !c->profiling;
     bool head_out = false;
     for (iteration = 1; iteration <= o->max_iter; ++iteration) {   // mod.rs:213
         if (!speculate) {
@@ -1205,7 +1250,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
             const size_t marks = c->nmarks;
             head_out = iteration < o->max_iter;
             if (head_out) LP_TRY(enqueue_head(c));
-            LP_HIP(hipEventSynchronize(c->ev_status));
+            LP_TRY(wait_status(c, nullptr, 1));
             prof_collect(c, marks);
             prof_collect_overlap(c, c->overlap_sections - (head_out ? 2 : 1));
         }
@@ -1321,7 +1366,7 @@ static lpipm_ctx* make_view(const lpipm_ctx* c, int first, int count) {
     v->va.bcount = count; v->va.bfirst = first; v->va.done_chk = c->va.done;
     v->status_cap = (size_t)count;
     if (hipStreamCreateWithFlags(&v->st, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&v->status_host, (size_t)count * sizeof(StatusRec)) != hipSuccess ||
+        hipHostMalloc((void**)&v->status_host, (size_t)count * sizeof(StatusRec), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void**)&v->timeout_host, sizeof(unsigned int)) != hipSuccess ||
         hipEventCreate(&v->ev_begin) != hipSuccess || hipEventCreate(&v->ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_status, hipEventDisableTiming) != hipSuccess) {
@@ -1332,6 +1377,9 @@ static lpipm_ctx* make_view(const lpipm_ctx* c, int first, int count) {
         return nullptr;
     }
     *v->timeout_host = 0;
+    std::memset(v->status_host, 0, (size_t)count * sizeof(StatusRec));
+    v->seq_counter = 0; v->spin_status = false;
+    bind_status_pinned(v, c->va.status_pinned != nullptr);
     return v;
 }
 
@@ -1420,6 +1468,7 @@ static int solve_lockstep_one(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo,
     std::vector<uint64_t> its((size_t)B, 0);
     int running = B, ip = o->ip ? 1 : 0;
     bool head_out = false;
+    c->spin_status = c->va.status_pinned != nullptr && !c->profiling;
     c->refine_now = c->refine == 2;      // (selective mode) at the starting point mu / mu_0 = 1: no member refines its first iteration
     for (uint64_t iteration = 1; iteration <= o->max_iter && running > 0; ++iteration) {   // mod.rs:213
         if (!head_out) LP_TRY(enqueue_head(c));
@@ -1427,7 +1476,11 @@ static int solve_lockstep_one(lpipm_ctx* c, const lpipm_opts* o, const XOut& xo,
         const size_t marks = c->nmarks;
         head_out = iteration < o->max_iter;
         if (head_out) LP_TRY(enqueue_head(c));       // next iteration's A.D.A^T, before this one's status is read
-        LP_HIP(hipEventSynchronize(c->ev_status));
+        {   // the members that were still running when this iteration was enqueued write a record; the others are skipped
+            std::vector<int> act;
+            for (int i = 0; i < B; ++i) if (ret[i] < 0) act.push_back(i);
+            LP_TRY(wait_status(c, act.data(), (int)act.size()));
+        }
         prof_collect(c, marks);
         ++batch_iterations;
         ip = 0;                                                              // mod.rs:223

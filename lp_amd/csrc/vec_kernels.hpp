@@ -44,6 +44,11 @@ struct VecArgs {
     const double* ATpart;  // [nsplit][nrhs][np] gemv_t slabs
     double *S, *red;
     StatusRec* status;
+    StatusRec* status_pinned;   // nullable: the context's coherent pinned host array, one record per LP of the launch (dense, index
+                                //   blockIdx.z).  The kernels that write `status` write the record here too -- payload, system
+                                //   fence, then the sequence word pad_ -- so the host can wait for an iteration by watching pad_:
+                                //   no D2H copy launch and no event record between the indicators and the next A.D.A^T
+    int status_seq;             // what pad_ is set to by the launch this argument block goes to
     int32_t *potrf_info;
     int *flags;
     int *skip_refine; // set by k_scalar_indicators: 1 = the refinement step of this LP's Cholesky solves is skipped in the next

@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 # The library ignores every one of them unless the master switch LPIPM_EXPERIMENTAL=1 is set (lp_knob, lpipm_internal.hpp).
 BIT_CHANGING_KNOBS = ("LPIPM_EXPERIMENTAL", "LPIPM_ADAT_KC", "LPIPM_ADAT_SK", "LPIPM_SUPER", "LPIPM_REFINE", "LPIPM_REFINE_BELOW",
                       "LPIPM_MERGE_EDGE", "LPIPM_OVERLAP", "LPIPM_OVERLAP_CUS", "LPIPM_LOOKAHEAD", "LPIPM_LOOKAHEAD_CUS",
-                      "LPIPM_GRAPH", "LPIPM_SPECULATE", "LPIPM_HALVES", "LPIPM_ADAT_UNITS", "LPIPM_VEC_FUSED")
+                      "LPIPM_GRAPH", "LPIPM_SPECULATE", "LPIPM_HALVES", "LPIPM_ADAT_UNITS", "LPIPM_VEC_FUSED", "LPIPM_STATUS_COPY")
 
 
 def pytest_configure(config):
