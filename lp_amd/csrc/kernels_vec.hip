@@ -543,7 +543,7 @@ constexpr int FUSED_USE_NBLK = 4;     // where they are used: n, m <= 1024.  One
                                       // its own: vector stage per iteration 0.070 -> 0.057 ms at 512x1024, but 0.102 -> 0.113
                                       // at 32 x (1024x2048) and 0.094 -> 0.383 at 4096x8192 (32 row-split slabs of A^T.v per
                                       // column through one CU)
-template <int K> struct FusedSm { double w[K][FUSED_MAX_NBLK][4]; double r[K][FUSED_MAX_NBLK]; };
+template <int K> struct FusedSm { double w[K][FUSED_MAX_NBLK][4]; };
 __device__ __forceinline__ VThread fused_thread(const VecArgs& a, int round) {
     return VThread{4 * round + (int)(threadIdx.x >> 8), (int)(threadIdx.x & 255), a.nblk};
 }
@@ -557,24 +557,22 @@ __device__ __forceinline__ void fused_wave_part(const double (&v)[K], FusedSm<K>
         if (lane == 0) sm.w[k][vb][vw] = w;
     }
 }
-// all parts in: every thread gets the K totals (same tree as block_reduce_store + fold_sum / fold_min)
+// all parts in: every thread gets the K totals (same tree as block_reduce_store + fold_sum / fold_min: every wave forms the
+// block sums of the blocks its lanes stand for and folds them itself -- ONE barrier; a FusedSm is used for one reduction only)
 template <int K, bool IS_MIN>
-__device__ __forceinline__ void fused_total(FusedSm<K>& sm, int nblk, double (&out)[K]) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * nblk; e += FUSED_THREADS) {
-        const int k = e / nblk, b = e - k * nblk;
-        const double* w = sm.w[k][b];
-        sm.r[k][b] = IS_MIN ? fmin(fmin(w[0], w[1]), fmin(w[2], w[3])) : (w[0] + w[1]) + (w[2] + w[3]);
-    }
+__device__ __forceinline__ void fused_total(const FusedSm<K>& sm, int nblk, double (&out)[K]) {
     __syncthreads();
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double s = IS_MIN ? 1.0 : 0.0;
-        if (lane < nblk) s = IS_MIN ? fmin(s, sm.r[k][lane]) : s + sm.r[k][lane];
+        if (lane < nblk) {
+            const double* w = sm.w[k][lane];
+            const double r = IS_MIN ? fmin(fmin(w[0], w[1]), fmin(w[2], w[3])) : (w[0] + w[1]) + (w[2] + w[3]);
+            s = IS_MIN ? fmin(s, r) : s + r;
+        }
         out[k] = IS_MIN ? wave_min(s) : wave_sum(s);
     }
-    __syncthreads();        // sm may be written again
 }
 
 // k_pq_uv -> d_tau (delta.rs:29-32,38) -> k_delta(0) -> alpha, gamma, eta (feasible_point.rs:134-136) -> k_corr_setup
@@ -623,7 +621,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_predictor(VecArgs a, in
 // k_uv_corr -> d_tau -> k_delta(1) -> the step length (mod.rs:216-221) -> do_step (feasible_point.rs:76-106) incl. tau, kappa
 __global__ __launch_bounds__(FUSED_THREADS) void k_fused_corrector(VecArgs a, int ip, double alpha0) {
     if (!vbatch(a, true)) return;
-    __shared__ FusedSm<2> sm2;
+    __shared__ FusedSm<2> sm2, sm2b;
     const int rounds = (a.nblk + 3) / 4;
     for (int r = 0; r < rounds; ++r) {
         const VThread t = fused_thread(a, r);
@@ -640,10 +638,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_corrector(VecArgs a, in
         if (t.vb >= a.nblk) continue;
         double mn[2] = {1.0, 1.0};
         body_delta(a, t, 1, o.d_tau, mn);
-        fused_wave_part<2, true>(mn, sm2, t.vb);
+        fused_wave_part<2, true>(mn, sm2b, t.vb);
     }
     double mins[2];
-    fused_total<2, true>(sm2, a.nblk, mins);
+    fused_total<2, true>(sm2b, a.nblk, mins);
     const double alpha = ip ? 1.0 : amin_from(a, mins[0], mins[1], o.d_tau, o.d_kappa) * alpha0;
     double tau = a.S[S_TAU] + o.d_tau * alpha;             // k_step_scalars
     double kappa = a.S[S_KAPPA] + o.d_kappa * alpha;
@@ -674,7 +672,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_fused_residuals(VecArgs a, in
         fused_wave_part<6, false>(acc, sm6, t.vb);
     }
     double tot[6];
-    fused_total<6, false>(sm6, a.nblk, tot);               // (its last barrier: every thread has read S[S_TAU])
+    fused_total<6, false>(sm6, a.nblk, tot);               // (behind its barrier: every thread has read S[S_TAU])
     if (threadIdx.x == 0) nd = scalar_indicators(a, is_init, ip_next, tol, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     if (!with_pred) return;
     __syncthreads();
