@@ -251,9 +251,10 @@ def measure_single(m, n, steps, warmup, c2, want_cpu_baseline, rank, local_rank,
     phase_iters = max(int(pt["iterations"]), 1)
     ctx.set_profiling(0)
     # config 2 is a chain of ~30 launches of 5-30 us per iteration: the event brackets of its phase split cost a visible share
-    # of it.  The same steps once more with no event recorded at all (every rank runs them: the step holds the gather)
+    # of it (at C3 the two events around A.D.A^T cost ~0.2 %).  The same steps once more with no event recorded at all
+    # (every rank runs them: the step holds the gather); `value` stays the bracketed measurement above
     unbracketed = None
-    if c2:
+    if True:
         barrier()
         t1 = time.perf_counter()
         its_u = 0
