@@ -417,6 +417,37 @@ def test_fused_vector_stage_is_bit_identical(built, monkeypatch, m, n, ip):
     assert np.array_equal(r0[1], r1[1]) and r0[4] == r1[4]
 
 
+def test_status_records_through_pinned_memory_equal_the_copied_ones(built, monkeypatch):
+    """The per-iteration status record (indicators.rs:8-23 + alpha) is written by k_scalar_indicators into the context's
+    pinned array behind a sequence word the host watches; LPIPM_STATUS_COPY=1 restores the D2H copy launch + event of
+    rounds 1-2.  Same iterates, same log, for a single solve, an infeasible one and a lockstep batch."""
+    import lp_amd
+    from lp_amd import synth
+    A, b, c = synth.planted_lp(5, 300, 700)[:3]
+    probs = [synth.planted_lp(s, 96, 200)[:3] for s in range(18)]
+    o = lp_amd.InteriorPoint.default().opts()
+
+    def run():
+        cx = lp_amd.Context(0)
+        cx.upload_arrays(A, b, c)
+        r = cx.solve_raw(o, want_log=True)
+        cx.upload_arrays(np.array([[1.0, 1.0], [1.0, 1.0]]), np.array([1.0, 2.0]), np.array([1.0, 1.0]))   # x1 + x2 = 1 and = 2
+        bad = cx.solve_raw(o)
+        cx.upload_lockstep([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs])
+        ls = cx.solve_lockstep(o)
+        cx.close()
+        return r, bad, ls
+
+    r0, bad0, ls0 = run()
+    monkeypatch.setenv("LPIPM_EXPERIMENTAL", "1")
+    monkeypatch.setenv("LPIPM_STATUS_COPY", "1")
+    r1, bad1, ls1 = run()
+    assert r0[0] == r1[0] == 0 and r0[3] == r1[3] and r0[4] == r1[4] and np.array_equal(r0[1], r1[1])
+    assert bad0[0] == bad1[0] != 0 and bad0[3] == bad1[3]
+    for a_, b_ in zip(ls0, ls1):
+        assert a_[0] == b_[0] == 0 and a_[3] == b_[3] and np.array_equal(a_[1], b_[1])
+
+
 @pytest.mark.parametrize("case", ["dup_rows", "dependent_row", "zero_row"])
 def test_rank_deficient_constraints_are_a_numerical_problem(ctx, case):
     """Linearly dependent rows make A.D.A^T singular: the reference's Cholesky fails and `solve` returns
