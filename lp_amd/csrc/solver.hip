@@ -1220,7 +1220,7 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     prof_mark(c, T_VEC);
     // the host needs the starting point's indicators only for the `disp` table, for the selective refinement's first decision
     // and for the phase marks: otherwise the first iteration is enqueued without a round trip to the host (~25 us per solve)
-    const bool need_start_row = o->disp || c->refine == 1 || c->profiling;
+    const bool need_start_row = o->disp || c->refine == 1 || c->profiling == 1;   // (profiling 2 brackets A.D.A^T only: no mark yet)
     if (need_start_row) {
         LP_HIP(hipStreamSynchronize(st));
         prof_collect(c);
@@ -1236,7 +1236,9 @@ static int solve_impl(lpipm_ctx* c, const lpipm_opts* o, double* x_host, void* x
     // the head of iteration k+1 goes out before the status of iteration k is read (see enqueue_head); not when the
     // iteration is replayed as a graph or contains host-side collectives
     const bool speculate = c->use_graph != 1 && !c->colsplit && !c->no_speculate;
-    c->spin_status = speculate && c->va.status_pinned != nullptr && !c->profiling;
+    // (with every phase bracketed -- profiling 1 -- the last mark of an iteration is recorded BEHIND the indicators kernel and
+    //  has to have completed when it is read: the event wait stays; profiling 2's two marks sit in front of it)
+    c->spin_status = speculate && c->va.status_pinned != nullptr && c->profiling != 1;
     bool head_out = false;
     for (iteration = 1; iteration <= o->max_iter; ++iteration) {   // mod.rs:213
         if (!speculate) {
